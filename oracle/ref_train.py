@@ -1,0 +1,300 @@
+"""CPU oracle: the loss functions and the five-phase training step of the reference.
+
+TEST INFRASTRUCTURE (see ``oracle/ref_model.py`` header for who may import it).
+Plain PyTorch-fp32 autograd on the CPU; every function cites what it restates.
+All random draws go through the global torch CPU generator in the reference's order
+(SURVEY.md §3.4), so with the same seed this reproduces the reference bit for bit on
+the same machine/thread count -- that is what ``tests/test_oracle_golden.py`` pins.
+"""
+import itertools
+
+import numpy as np
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from .ref_model import AE_CLASSES, DiscriminatorFC, gaussian_taps
+
+
+# ----------------------------------------------------------------------------- losses
+def kendall_constraint(descriptors, styles, activate=False):
+    """Pairwise sign-concordance loss, ``sc/utils/functions.py:37-79``.
+
+    Restated literally (materialised [B,B,n_aux]; boolean-mask in-place scaling) so
+    that the arithmetic -- including its float32 summation -- is the reference's.
+    """
+    n_aux = styles.shape[1]
+    target = torch.sign(descriptors[:, None, :] - descriptors[None, :, :])
+    pred = styles[:, None, :] - styles[None, :, :]
+    n = pred.size(0)
+    product = pred * target
+    if activate:
+        same = product > 0
+        opp = product < 0
+        idx = torch.arange(n_aux)
+        for k in range(n_aux):
+            sel = idx == k
+            n_same = max(torch.numel(product[same & sel]), 1)
+            n_opp = max(torch.numel(product[opp & sel]), 1)
+            product[same & sel] *= n_opp / max(n_same, n_opp)
+    return -product.sum() / ((n ** 2 - n) * n_aux)
+
+
+def kendall_closed_form(descriptors, styles, activate=False):
+    """One-pass closed form of the same loss and its gradient,
+    float64.  Returns ``(loss, dstyles)``.  This is the algorithm the HIP kernel
+    implements; ``tests/test_oracle_golden.py`` checks it against the literal form."""
+    d = descriptors.double()
+    z = styles.double()
+    n, k = z.shape
+    s = torch.sign(d[:, None, :] - d[None, :, :])
+    p = (z[:, None, :] - z[None, :, :]) * s
+    pos, neg = p > 0, p < 0
+    n_same = pos.sum((0, 1)).clamp(min=1).double()
+    n_opp = neg.sum((0, 1)).clamp(min=1).double()
+    c = n_opp / torch.maximum(n_same, n_opp) if activate else torch.ones(k, dtype=torch.float64)
+    norm = (n * n - n) * k
+    s_pos = (p * pos).sum((0, 1))
+    s_neg = (p * neg).sum((0, 1))
+    loss = -(c * s_pos + s_neg).sum() / norm
+    g_pos = (s * pos).sum(1)
+    g_neg = (s * neg).sum(1)
+    return loss, -(2.0 / norm) * (c * g_pos + g_neg)
+
+
+def recon_loss(spec_in, spec_out, scale=False):
+    """``sc/utils/functions.py:81-107``."""
+    spec_in = spec_in.clone()
+    if not scale:
+        return F.mse_loss(spec_out, spec_in)
+    ratio = torch.abs(spec_out.mean(dim=1)) / torch.abs(spec_in.mean(dim=1))
+    loss = ((ratio - 1.0) ** 2).mean() * 0.1
+    ratio = torch.clamp(ratio.detach(), min=0.7, max=1.3)
+    return loss + F.mse_loss(spec_out, (spec_in.T * ratio).T)
+
+
+def adversarial_loss(spec_in, styles, disc, alpha, batch_size):
+    """``sc/utils/functions.py:109-132`` (BCE-with-logits; real = N(0,I) of the
+    *configured* batch size, fake = encoder styles of the actual batch)."""
+    nstyle = styles.size(1)
+    z_real = torch.randn(batch_size, nstyle, requires_grad=True)
+    real_pred = disc(z_real, alpha)
+    fake_pred = disc(styles, alpha)
+    ones = torch.ones(batch_size, dtype=torch.float32)
+    zeros = torch.zeros(spec_in.size(0), dtype=torch.float32)
+    bce = nn.BCEWithLogitsLoss()
+    return bce(real_pred.squeeze(), ones) + bce(fake_pred.squeeze(), zeros)
+
+
+def mutual_info_loss(spec_in, styles, encoder, decoder):
+    """``sc/utils/functions.py:174-192``."""
+    z = torch.randn(spec_in.size(0), styles.size(1), requires_grad=False)
+    return F.mse_loss(encoder(decoder(z)), z)
+
+
+def smoothness_loss(spec_out, gs_kernel_size=17):
+    """``sc/utils/functions.py:194-212`` + ``GaussianSmoothing`` (``model.py:177-229``):
+    replicate-pad, 17-tap normalised Gaussian (sigma 3), MSE(x, smoothed x)."""
+    w = gaussian_taps(gs_kernel_size, 3.0).view(1, 1, -1)
+    pad = (gs_kernel_size - 1) // 2
+    padded = F.pad(spec_out.unsqueeze(1), (pad, pad), mode="replicate")
+    smoothed = F.conv1d(padded, w, groups=1).squeeze(1)
+    return F.mse_loss(spec_out, smoothed)
+
+
+def alpha(epoch_percentage, step=800, limit=0.7):
+    """``sc/utils/functions.py:214-219`` (float64 numpy)."""
+    return (2. / (1. + np.exp(-1.0E4 / step * epoch_percentage)) - 1) * limit
+
+
+# ----------------------------------------------------------------------------- data
+def split_rows(n_rows, ratios=(0.7, 0.15, 0.15)):
+    """Contiguous train/val/test split of ``sc/clustering/dataloader.py:14-20``."""
+    n = [int(n_rows * r) for r in ratios]
+    n[-1] = n_rows - sum(n[:-1])
+    return n
+
+
+def epoch_permutation(n_train):
+    """Row order of one epoch of ``DataLoader(shuffle=True, num_workers=0)``
+    (SURVEY.md finding 9): the iterator draws ``_base_seed`` (one int64 ``random_()``
+    from the global generator), the RandomSampler draws its own seed (a second one) and
+    permutes with a private generator."""
+    torch.empty((), dtype=torch.int64).random_()  # _base_seed
+    seed = int(torch.empty((), dtype=torch.int64).random_().item())
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return torch.randperm(n_train, generator=g)
+
+
+# ----------------------------------------------------------------------------- trainer
+class OracleTrainer:
+    """Restates ``Trainer.from_data`` + ``Trainer.train`` (``sc/clustering/trainer.py:38-474``)
+    for the reachable configuration set (SURVEY.md finding 4): ``ae_form`` in {FC, compact},
+    gradient reversal, ``DiscriminatorFC``, Adam/AdamW, ``n_aux >= 1``.
+
+    ``spec``/``aux`` are the full float64 arrays (what the reference reads from CSV).
+    """
+
+    metric_weights = [1.0, -1.0, -0.01, -1.0, -1.0]
+    gau_kernel_size = 17
+
+    def __init__(self, spec, aux, cfg, anomaly=False):
+        self.cfg = dict(cfg)
+        c = self.cfg
+        n_train, n_val, _ = split_rows(len(spec))
+        self.train_spec = np.asarray(spec[:n_train])
+        self.train_aux = np.asarray(aux[:n_train])
+        self.val_spec = torch.tensor(np.asarray(spec[n_train:n_train + n_val]), dtype=torch.float32)
+        self.val_aux = torch.tensor(np.asarray(aux[n_train:n_train + n_val]), dtype=torch.float32)
+        enc_cls, dec_cls = AE_CLASSES[c["ae_form"]]
+        # construction order enc -> dec -> D fixes the init draws (trainer.py:442-463)
+        self.encoder = enc_cls(nstyle=c["nstyle"], dropout_rate=c["dropout_rate"], dim_in=c["dim_in"],
+                               n_layers=c["n_layers"])
+        self.decoder = dec_cls(nstyle=c["nstyle"], dropout_rate=c["dropout_rate"],
+                               last_layer_activation=c["decoder_activation"], dim_out=c["dim_out"],
+                               n_layers=c["n_layers"])
+        self.discriminator = DiscriminatorFC(nstyle=c["nstyle"], dropout_rate=c["dis_dropout_rate"],
+                                             noise=c["dis_noise"], layers=c["FC_discriminator_layers"])
+        self.epoch_stop_smooth = c.get("epoch_stop_smooth", 500)
+        self._load_optimizers()
+        self.anomaly = anomaly
+        self.last = {}
+        self.phase_hook = None   # callable(phase_name) invoked after backward, before optimizer.step
+
+    # trainer.py:333-408
+    def _load_optimizers(self):
+        c = self.cfg
+        cls = {"Adam": torch.optim.Adam, "AdamW": torch.optim.AdamW}[c["optimizer_name"]]
+        enc, dec, dis = self.encoder, self.decoder, self.discriminator
+        lr = c["lr_base"]
+        betas_d = (c["dis_beta"] * 0.9, c["dis_beta"] * 0.009 + 0.99)
+        self.optimizers = {
+            "reconstruction": cls([{"params": enc.parameters()}, {"params": dec.parameters()}],
+                                  lr=c["lr_ratio_Reconn"] * lr, weight_decay=c["weight_decay"]),
+            "mutual_info": cls([{"params": enc.parameters()}, {"params": dec.parameters()}],
+                               lr=c["lr_ratio_Mutual"] * lr),
+            "smoothness": cls([{"params": dec.parameters()}], lr=c["lr_ratio_Smooth"] * lr,
+                              weight_decay=c["weight_decay"]),
+            "correlation": cls([{"params": enc.parameters()}], lr=c["lr_ratio_Corr"] * lr,
+                               weight_decay=c["weight_decay"]),
+            "adversarial": cls([{"params": dis.parameters()}, {"params": enc.parameters()}],
+                               lr=c["lr_ratio_dis"] * lr, betas=betas_d),
+        }
+        self.schedulers = {k: torch.optim.lr_scheduler.ReduceLROnPlateau(
+            o, mode="min", factor=c["sch_factor"], patience=c["sch_patience"], cooldown=0, threshold=0.01)
+            for k, o in self.optimizers.items()}
+
+    def zerograd(self):
+        for m in (self.encoder, self.decoder, self.discriminator):
+            m.zero_grad()
+
+    def _finish(self, name, loss):
+        loss.backward()
+        if self.phase_hook is not None:
+            self.phase_hook(name)
+        self.optimizers[name].step()
+
+    # trainer.py:103-204 -- one batch through the five phases
+    def train_step(self, spec_in, aux_in, alpha_, epoch=0):
+        c = self.cfg
+        enc, dec, dis = self.encoder, self.decoder, self.discriminator
+        n_aux = aux_in.size(-1)
+        spec_in += torch.randn_like(spec_in, requires_grad=False) * c["spec_noise"]
+        styles = enc(spec_in)
+        dec(styles)  # result unused by the reference too, but advances BN stats and the RNG
+        out = {}
+        self.zerograd()
+        loss = adversarial_loss(spec_in, styles, dis, alpha_, batch_size=c["batch_size"])
+        self._finish("adversarial", loss)
+        out["adversarial"] = loss
+        self.zerograd()
+        styles = enc(spec_in)
+        loss = kendall_constraint(aux_in, styles[:, :n_aux], activate=c["kendall_activation"])
+        self._finish("correlation", loss)
+        out["kendall"] = loss
+        self.zerograd()
+        loss = recon_loss(spec_in, dec(enc(spec_in)), scale=c["use_flex_spec_target"])
+        self._finish("reconstruction", loss)
+        out["recon"] = loss
+        self.zerograd()
+        styles = enc(spec_in)
+        loss = mutual_info_loss(spec_in, styles, enc, dec)
+        self._finish("mutual_info", loss)
+        out["mutual_info"] = loss
+        if epoch < self.epoch_stop_smooth:
+            self.zerograd()
+            loss = smoothness_loss(dec(enc(spec_in)), self.gau_kernel_size)
+            self._finish("smoothness", loss)
+            out["smooth"] = loss
+        else:
+            out["smooth"] = torch.tensor(0)
+        self.zerograd()
+        self.last = {k: float(v.detach()) for k, v in out.items()}
+        return self.last
+
+    # trainer.py:206-268
+    def validate(self, alpha_):
+        c = self.cfg
+        enc, dec, dis = self.encoder, self.decoder, self.discriminator
+        for m in (enc, dec, dis):
+            m.eval()
+        torch.empty((), dtype=torch.int64).random_()  # val DataLoader iterator's _base_seed draw
+        z = enc(self.val_spec)
+        spec_out = dec(z)
+        n_aux = self.val_aux.size(-1)
+        val = {
+            "recon": recon_loss(self.val_spec, spec_out),
+            "kendall": kendall_constraint(self.val_aux, z[:, :n_aux], activate=c["kendall_activation"]),
+            "smooth": smoothness_loss(spec_out, self.gau_kernel_size),
+            "mutual_info": mutual_info_loss(self.val_spec, z, enc, dec),
+            "adversarial": adversarial_loss(self.val_spec, z, dis, alpha_, batch_size=c["batch_size"]),
+        }
+        return z, {k: float(v.detach()) for k, v in val.items()}
+
+    def train(self, max_epoch=None, callback=None, record=None):
+        """Full loop incl. validation + scipy metrics + schedulers; ``record`` (dict of
+        lists) receives every loss call in the order the golden fixtures store them."""
+        from scipy.stats import shapiro, spearmanr
+        c = self.cfg
+        max_epoch = c["max_epoch"] if max_epoch is None else max_epoch
+        metrics = None
+        prev_anomaly = torch.is_anomaly_enabled()
+        torch.autograd.set_detect_anomaly(self.anomaly)
+        n_train = len(self.train_spec)
+        bs = c["batch_size"]
+        for epoch in range(max_epoch):
+            for m in (self.encoder, self.decoder, self.discriminator):
+                m.train()
+            alpha_ = alpha(epoch / max_epoch, c["alpha_flat_step"], c["alpha_limit"])
+            perm = epoch_permutation(n_train).numpy()
+            n_batch = -(-n_train // bs)
+            avg_mi = 0.0
+            for ib in range(n_batch):
+                rows = perm[ib * bs:(ib + 1) * bs]
+                spec_in = torch.tensor(self.train_spec[rows], dtype=torch.float32)
+                aux_in = torch.tensor(self.train_aux[rows], dtype=torch.float32)
+                losses = self.train_step(spec_in, aux_in, alpha_, epoch)
+                avg_mi += losses["mutual_info"]
+                if record is not None:
+                    for k in ("adversarial", "kendall", "recon", "mutual_info"):
+                        record[k].append(losses[k])
+                    if epoch < self.epoch_stop_smooth:
+                        record["smooth"].append(losses["smooth"])
+            z, val = self.validate(alpha_)
+            if record is not None:
+                for k in ("recon", "kendall", "smooth", "mutual_info", "adversarial"):
+                    record[k].append(val[k])
+            avg_mi /= n_batch
+            style_np = z.detach().clone().numpy().T
+            sh = [shapiro(x).statistic for x in style_np]
+            coupling = np.max(np.fabs([spearmanr(style_np[a], style_np[b]).correlation
+                                       for a, b in itertools.combinations(range(style_np.shape[0]), 2)]))
+            metrics = [min(sh), val["recon"], avg_mi, coupling, val["kendall"]]
+            combined = -(np.array(self.metric_weights) * np.array(metrics)).sum()
+            for sch in self.schedulers.values():
+                sch.step(combined)
+            if callback is not None:
+                callback(epoch, metrics)
+        torch.autograd.set_detect_anomaly(prev_anomaly)
+        return metrics
