@@ -1,0 +1,181 @@
+/* rankaae_hip.h -- C ABI of librankaae_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (AI-multimodal/RankAAE) has no FFI: its hot path is eager PyTorch.
+ * Each entry point below replaces a chain of ATen ops *plus its autograd backward*
+ * in the reference file:line cited.  Conventions:
+ *   - every pointer is a DEVICE pointer (fp32 unless said otherwise); no allocation,
+ *     no host synchronisation inside; work is enqueued on `stream` (a hipStream_t);
+ *   - return value: 0 on success, a hipError_t (>0) from the launch, or
+ *     RAAE_EINVAL (-1) when host-side shape validation fails (nothing is launched);
+ *   - reductions that cross workgroups use fixed-order partial buffers, never float
+ *     atomics, so every result is bitwise reproducible run to run.
+ *
+ * Batch-norm convention ("raw + partials"): a producing kernel stores the RAW tensor
+ * and per-workgroup partial sums {sum, sum of squares} (double) of what the following
+ * BatchNorm1d(affine=False) sees; the consuming kernel reduces those partials in its
+ * prologue (train mode, biased variance, eps) or takes running statistics (eval mode).
+ */
+#ifndef RANKAAE_HIP_H
+#define RANKAAE_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAAE_EINVAL (-1)
+#define RAAE_MAX_PARTS 512      /* max partial-sum rows any producer may emit */
+
+/* Source of BatchNorm statistics for a consumer (torch.nn.BatchNorm1d(affine=False),
+ * sc/clustering/model.py:29,35,49,110,116,130,250,284,349,358,366,460,543,552). */
+typedef struct {
+    const double* partials;   /* [nparts][C][2] {sum, sumsq}; NULL => eval mode (use running stats) */
+    int nparts;
+    float count;              /* elements per channel behind the partials (B*L) */
+    float* running_mean;      /* [C]; read in eval mode; updated in train mode iff update_running */
+    float* running_var;       /* [C] */
+    float momentum;           /* 0.1 */
+    float eps;                /* 1e-5 */
+    int update_running;       /* exactly one consumer of a BN layer per forward sets this */
+} raae_bn_t;
+
+/* ---- input transform applied while loading a dense layer's input ---- */
+enum { RAAE_IN_NONE = 0, RAAE_IN_PRELU_BN_DROP = 1, RAAE_IN_PRELU_DROP = 2 };
+/* ---- what the dense layer's output feeds ---- */
+enum { RAAE_OUT_RAW = 0,          /* store z; no statistics */
+       RAAE_OUT_STATS_PRELU = 1,  /* store z; partials of PReLU(z)   (Linear->PReLU->BN) */
+       RAAE_OUT_STATS_RAW = 2,    /* store z; partials of z          (Linear->BN)        */
+       RAAE_OUT_SOFTPLUS = 3,     /* store softplus_beta2(z)         (decoder output)    */
+       RAAE_OUT_RELU = 4 };       /* store relu(z) */
+
+/* Fused  [PReLU -> BatchNorm -> Dropout] -> Linear  forward on the matrix cores
+ * (v_mfma_f32_16x16x4_f32: exact fp32).  Replaces nn.Linear + the preceding
+ * PReLU/BatchNorm1d/Dropout modules of FCEncoder / FCDecoder / DiscriminatorFC
+ * (sc/clustering/model.py:346-371, 540-563, 635-653) and lin3 (model.py:283).
+ *   x      [B][K]  raw output of the previous layer (or the network input)
+ *   slope  [K]     PReLU slopes of the previous layer      (in_kind != NONE)
+ *   bn             statistics of PReLU(x)                  (in_kind == PRELU_BN_DROP)
+ *   mask   [B][K]  dropout scale {0, 1/(1-p)} or NULL
+ *   w [N][K], bias [N]; z [B][N] output
+ *   out_slope [N]  PReLU slopes of THIS layer (out_kind == STATS_PRELU)
+ *   out_partials   [grid_x][N][2] doubles; *out_nparts receives grid_x (host int)
+ */
+int raae_dense_fwd(const float* x, int B, int K, int in_kind, const float* slope, const raae_bn_t* bn,
+                   const float* mask, const float* w, const float* bias, int N, float* z, int out_kind,
+                   const float* out_slope, double* out_partials, int* out_nparts, void* stream);
+
+/* how the gradient w.r.t. this layer's raw output z is obtained in the prologue */
+enum { RAAE_G_DIRECT = 0,        /* g is dL/dz                                                  */
+       RAAE_G_SOFTPLUS = 1,      /* g is dL/d softplus(z); `zout` holds softplus(z)             */
+       RAAE_G_PRELU_BN = 2,      /* g is dL/dy, y = BN(PReLU(z)); needs g_partials, z, bn, slope */
+       RAAE_G_PRELU = 3,         /* g is dL/d PReLU(z) (no BN: discriminator)                   */
+       RAAE_G_RELU = 4 };
+
+/* Backward of the same fused layer: dW, dbias, dslope (fixed-order slabs, one per
+ * workgroup), and -- if dx != NULL -- dL/d(input after its transform's BatchNorm),
+ * i.e. dx = (g_z . W) * mask, together with the partial sums {sum dx, sum dx*y_in}
+ * that the previous layer's RAAE_G_PRELU_BN prologue needs (autograd of
+ * nn.Linear/PReLU/BatchNorm1d/Dropout; torch semantics).
+ *   g [B][N], g_partials [g_nparts][N][2] ({sum g, sum g*y}), zout [B][N] = this layer's stored output
+ *   out_slope [N], out_bn: this layer's own PReLU/BN (for the prologue)
+ *   x, in_kind, slope, bn, mask: as in forward (recomputes the layer input)
+ *   dw_slab [nslab][slab_stride] base pointers already offset to this tensor:
+ *       dW at dw, dbias at db, dslope at dslope (may be NULL when out has no PReLU)
+ *   dx [B][K] or NULL; dx_partials [grid][K][2] or NULL (needed iff in_kind==PRELU_BN_DROP)
+ *   *nslab receives the number of slabs written (= grid size).
+ */
+int raae_dense_bwd(const float* g, int g_kind, const double* g_partials, int g_nparts, const float* zout,
+                   const float* out_slope, const raae_bn_t* out_bn, int B, int N,
+                   const float* x, int K, int in_kind, const float* slope, const raae_bn_t* bn,
+                   const float* mask, const float* w,
+                   float* dw, float* db, float* dslope, long slab_stride, int* nslab,
+                   float* dx, double* dx_partials, void* stream);
+
+/* Final BatchNorm1d(nstyle, affine=False) of both encoders (model.py:284,366):
+ * styles = BN(z).  Backward: dz from dstyles (torch batch_norm backward, train mode). */
+int raae_style_bn_fwd(const float* z, int B, int C, const raae_bn_t* bn, float* styles, void* stream);
+int raae_style_bn_bwd(const float* dstyles, const float* styles, int B, int C, const raae_bn_t* bn,
+                      float scale, float* dz, void* stream);
+
+/* Pairwise sign-concordance ("Kendall") loss and its gradient in ONE pass over the
+ * B^2 pairs, never materialising [B,B,n_aux] (sc/utils/functions.py:37-79 + autograd).
+ *   d [B][ldd] descriptors, z [B][ldz] styles (first n_aux columns are used)
+ *   work: >= raae_rank_loss_work_bytes(B, n_aux) bytes of scratch
+ *   loss: 1 float; dz [B][ldz] (columns >= n_aux are zeroed) or NULL (validation). */
+long raae_rank_loss_work_bytes(int B, int n_aux);
+int raae_rank_loss_fwd_bwd(const float* d, int ldd, const float* z, int ldz, int B, int n_aux, int activate,
+                           void* work, float* loss, float* dz, void* stream);
+
+/* recon_loss (functions.py:81-107): scale!=0 => "flexible target" branch.
+ * partial: [>= grid] doubles (fixed-order loss partials); *nparts = grid. dout may be NULL. */
+int raae_recon_loss_fwd_bwd(const float* spec_in, const float* spec_out, int B, int L, int scale,
+                            double* partial, int* nparts, float* dout, void* stream);
+
+/* smoothness_loss (functions.py:194-212, model.py:177-229): replicate pad, `ntaps`-tap
+ * normalised Gaussian (taps given by the host), MSE(x, G x); gradient through both operands. */
+int raae_smooth_loss_fwd_bwd(const float* x, int B, int L, const float* taps, int ntaps,
+                             double* partial, int* nparts, float* dx, void* stream);
+
+/* nn.MSELoss (mutual_info_loss, functions.py:187-190): mean((a-b)^2), da = 2(a-b)/n. */
+int raae_mse_fwd_bwd(const float* a, const float* b, long n, double* partial, int* nparts, float* da, void* stream);
+
+/* BCEWithLogitsLoss(real,1) + BCEWithLogitsLoss(fake,0), each mean-reduced over its
+ * own count (functions.py:119-130).  logits [n_real + n_fake]; dlogits same shape. */
+int raae_bce_pair_fwd_bwd(const float* logits, int n_real, int n_fake, float* loss, float* dlogits, void* stream);
+
+/* Discriminator input: rows [0,n_real) = z_real + sigma*noise, rows [n_real, n_real+n_fake) =
+ * styles + sigma*noise (model.py:658-661; noise==NULL in eval mode). */
+int raae_disc_input(const float* z_real, const float* styles, const float* noise, float sigma,
+                    int n_real, int n_fake, int C, float* out, void* stream);
+/* dst[i] = scale * src[i]  (gradient reversal: scale = -alpha, model.py:15-22; alpha read from device) */
+int raae_scale_by_dev(const float* src, const float* dev_scale, float sign, long n, float* dst, void* stream);
+
+/* sums fixed-order partial buffers into loss slots: out[slot] = scale * sum(partial[0..n)),
+ * optionally accumulating out[acc_slot] += out[slot] (avg_mutual_info, trainer.py:186). */
+int raae_loss_finalize(const double* partial, int n, float scale, float* out, int slot, int acc_slot, void* stream);
+
+/* Batch assembly from the device-resident dataset: rows idx[cursor-B .. cursor) (cursor: device int,
+ * already advanced past this batch by raae_step_tick; NULL => idx[0..B)) -> spec_out, aux_out;
+ * spec_out += noise * spec_noise (dataloader.py:46-61 + trainer.py:112). */
+int raae_gather_batch(const float* spec, const float* aux, const long* idx, const int* cursor, const float* noise,
+                      float spec_noise, int B, int L, int n_aux, float* spec_out, float* aux_out, void* stream);
+
+/* Fused multi-tensor Adam/AdamW over a flat arena (torch.optim.Adam/AdamW single-tensor
+ * formulas, operation order mirrored in fp32; trainer.py:333-397).  Gradient of element i =
+ * fixed-order sum of seg_nslab[i/64] slabs; 0 slabs => skipped (like a param with .grad None).
+ *   p, m, v: base pointers of the optimizer's contiguous arena range, n floats (multiple of 64)
+ *   g_slabs: slab 0 of the same range; slab s at g_slabs + s*slab_stride
+ *   hyper (device, 5 doubles): {lr, beta1, beta2, eps, weight_decay}
+ *   step  (device int): 1-based step count, advanced by raae_step_tick BEFORE this launch
+ *   decoupled=1 => AdamW (p *= 1-lr*wd), 0 => Adam (g += wd*p). */
+int raae_adam_step(float* p, float* m, float* v, const float* g_slabs, long slab_stride, const unsigned char* seg_nslab,
+                   long n, const double* hyper, const int* step, int decoupled, void* stream);
+/* once per training step: steps[i] += 1 for every bit i set in mask; rng_counter[0] += 1;
+ * cursor[0] += cursor_inc (epoch row cursor of raae_gather_batch) */
+int raae_step_tick(int* steps, int n, unsigned mask, unsigned long long* rng_counter, int* cursor, int cursor_inc,
+                   void* stream);
+
+/* Philox4x32-10 fill of the per-step random tape (speed mode; parity mode uploads a tape drawn
+ * on the host in the reference's order).  seg_desc (device): [nseg][4] ints
+ * {offset, count, kind (0 = N(0,1), 1 = dropout scale {0,1/keep}), 0}, offsets multiples of 4,
+ * ascending; seg_scale (device) [nseg] = keep probability for kind 1; counter (device) = step index. */
+int raae_rng_fill(float* tape, const int* seg_desc, const float* seg_scale, int nseg, long total,
+                  unsigned long long seed, const unsigned long long* counter, void* stream);
+
+/* ---- stream / graph / event plumbing (HIP runtime; used by the engine and bench.py) ---- */
+int raae_graph_begin(void* stream);
+int raae_graph_end(void* stream, void** graph_exec);
+int raae_graph_launch(void* graph_exec, void* stream);
+int raae_graph_destroy(void* graph_exec);
+int raae_event_create(void** ev);
+int raae_event_record(void* ev, void* stream);
+int raae_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises on `stop` */
+int raae_event_destroy(void* ev);
+int raae_stream_sync(void* stream);
+const char* raae_error_string(int code);
+int raae_device_info(int* cu_count, int* lds_bytes, char* name, int name_len);
+int raae_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

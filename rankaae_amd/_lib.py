@@ -1,0 +1,94 @@
+"""ctypes binding of ``librankaae_hip.so`` (C ABI declared in ``include/rankaae_hip.h``).
+
+There is NO fallback: if the library is missing or a call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librankaae_hip.so")
+
+RAAE_MAX_PARTS = 512
+IN_NONE, IN_PRELU_BN_DROP, IN_PRELU_DROP = 0, 1, 2
+OUT_RAW, OUT_STATS_PRELU, OUT_STATS_RAW, OUT_SOFTPLUS, OUT_RELU = 0, 1, 2, 3, 4
+G_DIRECT, G_SOFTPLUS, G_PRELU_BN, G_PRELU, G_RELU = 0, 1, 2, 3, 4
+
+
+class BnT(C.Structure):
+    """``raae_bn_t``"""
+    _fields_ = [("partials", C.c_void_p), ("nparts", C.c_int), ("count", C.c_float),
+                ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
+                ("momentum", C.c_float), ("eps", C.c_float), ("update_running", C.c_int)]
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+class HipCallError(RuntimeError):
+    pass
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
+_PI = C.POINTER(C.c_int)
+_PB = C.POINTER(BnT)
+
+# name -> (restype, argtypes); every symbol include/rankaae_hip.h declares
+SIGNATURES = {
+    "raae_dense_fwd": (_I, [_P, _I, _I, _I, _P, _PB, _P, _P, _P, _I, _P, _I, _P, _P, _PI, _P]),
+    "raae_dense_bwd": (_I, [_P, _I, _P, _I, _P, _P, _PB, _I, _I, _P, _I, _I, _P, _PB, _P, _P,
+                            _P, _P, _P, _L, _PI, _P, _P, _P]),
+    "raae_style_bn_fwd": (_I, [_P, _I, _I, _PB, _P, _P]),
+    "raae_style_bn_bwd": (_I, [_P, _P, _I, _I, _PB, _F, _P, _P]),
+    "raae_rank_loss_work_bytes": (_L, [_I, _I]),
+    "raae_rank_loss_fwd_bwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "raae_recon_loss_fwd_bwd": (_I, [_P, _P, _I, _I, _I, _P, _PI, _P, _P]),
+    "raae_smooth_loss_fwd_bwd": (_I, [_P, _I, _I, C.POINTER(C.c_float), _I, _P, _PI, _P, _P]),
+    "raae_mse_fwd_bwd": (_I, [_P, _P, _L, _P, _PI, _P, _P]),
+    "raae_bce_pair_fwd_bwd": (_I, [_P, _I, _I, _P, _P, _P]),
+    "raae_disc_input": (_I, [_P, _P, _P, _F, _I, _I, _I, _P, _P]),
+    "raae_scale_by_dev": (_I, [_P, _P, _F, _L, _P, _P]),
+    "raae_loss_finalize": (_I, [_P, _I, _F, _P, _I, _I, _P]),
+    "raae_gather_batch": (_I, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P]),
+    "raae_adam_step": (_I, [_P, _P, _P, _P, _L, _P, _L, _P, _P, _I, _P]),
+    "raae_step_tick": (_I, [_P, _I, C.c_uint, _P, _P, _I, _P]),
+    "raae_rng_fill": (_I, [_P, _P, _P, _I, _L, C.c_ulonglong, _P, _P]),
+    "raae_graph_begin": (_I, [_P]),
+    "raae_graph_end": (_I, [_P, C.POINTER(C.c_void_p)]),
+    "raae_graph_launch": (_I, [_P, _P]),
+    "raae_graph_destroy": (_I, [_P]),
+    "raae_event_create": (_I, [C.POINTER(C.c_void_p)]),
+    "raae_event_record": (_I, [_P, _P]),
+    "raae_event_elapsed_ms": (_I, [_P, _P, C.POINTER(C.c_float)]),
+    "raae_event_destroy": (_I, [_P]),
+    "raae_stream_sync": (_I, [_P]),
+    "raae_error_string": (C.c_char_p, [_I]),
+    "raae_device_info": (_I, [_PI, _PI, C.c_char_p, _I]),
+    "raae_abi_version": (_I, []),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and attach prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            f"{LIB_PATH} not found: build it with rankaae_amd/csrc/build.sh (or __graft_entry__.build()). "
+            "rankaae_amd has no CPU or PyTorch fallback for the training path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what=""):
+    if code != 0:
+        msg = load().raae_error_string(int(code))
+        raise HipCallError(f"{what}: error {code}: {msg.decode() if msg else '?'}")

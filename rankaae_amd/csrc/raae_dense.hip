@@ -1,0 +1,402 @@
+// Fused dense layers on the CDNA4 matrix cores (v_mfma_f32_16x16x4_f32 -- exact fp32,
+// bit-for-bit a k-ordered fmaf chain), forward and backward.
+//
+// Replaces, per call, the ATen chain  PReLU -> BatchNorm1d(affine=False) -> Dropout ->
+// Linear (+ output activation) of FCEncoder / FCDecoder / DiscriminatorFC
+// (reference sc/clustering/model.py:346-371, 540-563, 635-653) and its autograd backward.
+//
+// Data layout: activations row-major [B][features]; weights [N][K] (torch nn.Linear).
+// A workgroup = 4 waves; it owns 16-row tiles of the batch (grid-stride) and, in the
+// forward, a group of 64 output columns (one 16x16 MFMA tile per wave).  BatchNorm
+// statistics and parameter gradients leave the kernel as fixed-order per-workgroup
+// partials (double) / slabs (float): no atomics, bitwise reproducible.
+#include "raae_common.h"
+
+namespace {
+
+using raae::prelu;
+
+struct DenseFwdArgs {
+    const float* x; int B; int K; int in_kind; const float* slope; raae_bn_t bn; const float* mask;
+    const float* w; const float* bias; int N; float* z; int out_kind; const float* out_slope;
+    double* out_partials; int KC; int pitch; int resident;
+};
+
+// dynamic LDS: s_mean[K4] s_rstd[K4] s_slope[K4] | Ws[64][pitch] | Xs[16][pitch]
+__global__ __launch_bounds__(256) void dense_fwd_kernel(DenseFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int K4 = (a.K + 3) & ~3;
+    float* s_mean = smem;
+    float* s_rstd = s_mean + K4;
+    float* s_slope = s_rstd + K4;
+    float* Ws = s_slope + K4;
+    float* Xs = Ws + 64 * a.pitch;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n0 = blockIdx.y * 64;
+
+    if (a.in_kind == RAAE_IN_PRELU_BN_DROP) {
+        raae::bn_prologue(a.bn, a.K, s_mean, s_rstd, blockIdx.x == 0 && blockIdx.y == 0);
+    }
+    if (a.in_kind != RAAE_IN_NONE) {
+        for (int k = tid; k < a.K; k += 256) s_slope[k] = a.slope[k];
+    }
+    __syncthreads();
+
+    const int ntiles = (a.B + 15) >> 4;
+    const int col = n0 + wv * 16 + (lane & 15);
+    const float bias = (col < a.N) ? a.bias[col] : 0.f;
+    const float oslope = (a.out_kind == RAAE_OUT_STATS_PRELU && col < a.N) ? a.out_slope[col] : 1.f;
+    double s_acc = 0.0, q_acc = 0.0;
+    bool w_staged = false;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile << 4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int kc0 = 0; kc0 < K4; kc0 += a.KC) {
+            const int kcur = min(a.KC, K4 - kc0);
+            if (!(a.resident && w_staged)) {
+                for (int idx = tid; idx < 64 * kcur; idx += 256) {
+                    const int c = idx / kcur, kk = idx - c * kcur;
+                    const int n = n0 + c, k = kc0 + kk;
+                    Ws[c * a.pitch + kk] = (n < a.N && k < a.K) ? a.w[(size_t)n * a.K + k] : 0.f;
+                }
+                w_staged = true;
+            }
+            for (int idx = tid; idx < 16 * kcur; idx += 256) {
+                const int r = idx / kcur, kk = idx - r * kcur;
+                const int row = row0 + r, k = kc0 + kk;
+                float v = 0.f;
+                if (row < a.B && k < a.K) {
+                    v = a.x[(size_t)row * a.K + k];
+                    if (a.in_kind != RAAE_IN_NONE) {
+                        v = prelu(v, s_slope[k]);
+                        if (a.in_kind == RAAE_IN_PRELU_BN_DROP) v = (v - s_mean[k]) * s_rstd[k];
+                        if (a.mask) v *= a.mask[(size_t)row * a.K + k];
+                    }
+                }
+                Xs[r * a.pitch + kk] = v;
+            }
+            __syncthreads();
+            const float* xa = Xs + (lane & 15) * a.pitch + (lane >> 4);
+            const float* wb = Ws + (wv * 16 + (lane & 15)) * a.pitch + (lane >> 4);
+            for (int kk = 0; kk < kcur; kk += 4) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kk], wb[kk], acc, 0, 0, 0);
+            }
+            __syncthreads();
+        }
+        // epilogue: lane holds rows row0 + (lane>>4)*4 + j of column `col`
+        if (col < a.N) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = row0 + (lane >> 4) * 4 + j;
+                if (row < a.B) {
+                    const float zv = acc[j] + bias;
+                    float o = zv;
+                    if (a.out_kind == RAAE_OUT_SOFTPLUS) o = raae::softplus2(zv);
+                    else if (a.out_kind == RAAE_OUT_RELU) o = fmaxf(zv, 0.f);
+                    a.z[(size_t)row * a.N + col] = o;
+                    if (a.out_kind == RAAE_OUT_STATS_PRELU || a.out_kind == RAAE_OUT_STATS_RAW) {
+                        const float v = (a.out_kind == RAAE_OUT_STATS_PRELU) ? prelu(zv, oslope) : zv;
+                        s_acc += (double)v;
+                        q_acc += (double)v * (double)v;
+                    }
+                }
+            }
+        }
+    }
+    if (a.out_kind == RAAE_OUT_STATS_PRELU || a.out_kind == RAAE_OUT_STATS_RAW) {
+        s_acc += __shfl_xor(s_acc, 16, 64); q_acc += __shfl_xor(q_acc, 16, 64);
+        s_acc += __shfl_xor(s_acc, 32, 64); q_acc += __shfl_xor(q_acc, 32, 64);
+        if (lane < 16 && col < a.N) {
+            double* p = a.out_partials + ((size_t)blockIdx.x * a.N + col) * 2;
+            p[0] = s_acc; p[1] = q_acc;
+        }
+    }
+}
+
+struct DenseBwdArgs {
+    const float* g; int g_kind; const double* g_partials; int g_nparts; const float* zout;
+    const float* out_slope; raae_bn_t out_bn; int B; int N;
+    const float* x; int K; int in_kind; const float* slope; raae_bn_t bn; const float* mask; const float* w;
+    float* dw; float* db; float* dslope; long slab_stride; float* dx; double* dx_partials;
+    int pitch_g; int pitch_x;
+};
+
+// TPW: 16x16 dW tiles per wave; KT4: 16-column dx tiles per wave.
+// LDS: o_mean[N16] o_rstd[N16] o_slope[N16] m1[N16] m2[N16] | i_mean[K16] i_rstd[K16] i_slope[K16]
+//      | Gs[16][pitch_g] | Xs[16][pitch_x] | red[2][256]
+template <int TPW, int KT4>
+__global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int N16 = (a.N + 15) & ~15, K16 = (a.K + 15) & ~15;
+    float* o_mean = smem;
+    float* o_rstd = o_mean + N16;
+    float* o_slope = o_rstd + N16;
+    float* m1 = o_slope + N16;
+    float* m2 = m1 + N16;
+    float* i_mean = m2 + N16;
+    float* i_rstd = i_mean + K16;
+    float* i_slope = i_rstd + K16;
+    float* Gs = i_slope + K16;
+    float* Xs = Gs + 16 * a.pitch_g;
+    float* red = Xs + 16 * a.pitch_x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int NT = N16 >> 4, KT = K16 >> 4;
+
+    if (a.g_kind == RAAE_G_PRELU_BN) {
+        raae::bn_prologue(a.out_bn, a.N, o_mean, o_rstd, false);
+        raae::bnbwd_prologue(a.g_partials, a.g_nparts, a.N, a.out_bn.count, m1, m2);
+    }
+    if (a.g_kind == RAAE_G_PRELU_BN || a.g_kind == RAAE_G_PRELU)
+        for (int n = tid; n < a.N; n += 256) o_slope[n] = a.out_slope[n];
+    if (a.in_kind == RAAE_IN_PRELU_BN_DROP) raae::bn_prologue(a.bn, a.K, i_mean, i_rstd, false);
+    if (a.in_kind != RAAE_IN_NONE)
+        for (int k = tid; k < a.K; k += 256) i_slope[k] = a.slope[k];
+    __syncthreads();
+
+    f32x4 wacc[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) wacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    double dxs[KT4], dxq[KT4];
+#pragma unroll
+    for (int i = 0; i < KT4; ++i) { dxs[i] = 0.0; dxq[i] = 0.0; }
+    // G staging: thread owns column(s) n = tid (+256) when N > 64, else n = tid % 64 with row phase tid/64
+    const bool wideN = a.N > 64;
+    const int gcol0 = wideN ? tid : (tid & 63);
+    const int grow0 = wideN ? 0 : (tid >> 6);
+    const int grstep = wideN ? 1 : 4;
+    float db_acc[2] = {0.f, 0.f}, ds_acc[2] = {0.f, 0.f};
+
+    const int ntiles = (a.B + 15) >> 4;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile << 4;
+        // ---- 1. dL/dz tile -> Gs (zero padded) ----
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int n = gcol0 + h * 256;
+            if (h == 1 && !(wideN && n < N16)) break;
+            if (n >= N16) continue;
+            for (int r = grow0; r < 16; r += grstep) {
+                const int row = row0 + r;
+                float dz = 0.f;
+                if (row < a.B && n < a.N) {
+                    const size_t o = (size_t)row * a.N + n;
+                    const float gv = a.g[o];
+                    if (a.g_kind == RAAE_G_DIRECT) dz = gv;
+                    else if (a.g_kind == RAAE_G_SOFTPLUS) dz = gv * (1.f - expf(-2.f * a.zout[o]));
+                    else if (a.g_kind == RAAE_G_RELU) dz = a.zout[o] > 0.f ? gv : 0.f;
+                    else {
+                        const float zv = a.zout[o];
+                        float da = gv;
+                        if (a.g_kind == RAAE_G_PRELU_BN) {
+                            const float y = (prelu(zv, o_slope[n]) - o_mean[n]) * o_rstd[n];
+                            da = o_rstd[n] * (gv - m1[n] - y * m2[n]);
+                        }
+                        if (zv > 0.f) dz = da;
+                        else { dz = da * o_slope[n]; ds_acc[h] += da * zv; }
+                    }
+                    db_acc[h] += dz;
+                }
+                Gs[r * a.pitch_g + n] = dz;
+            }
+        }
+        // ---- 2. layer input tile -> Xs (transform applied, zero padded) ----
+        for (int idx = tid; idx < 16 * K16; idx += 256) {
+            const int r = idx / K16, k = idx - r * K16;
+            const int row = row0 + r;
+            float v = 0.f;
+            if (row < a.B && k < a.K) {
+                v = a.x[(size_t)row * a.K + k];
+                if (a.in_kind != RAAE_IN_NONE) {
+                    v = prelu(v, i_slope[k]);
+                    if (a.in_kind == RAAE_IN_PRELU_BN_DROP) v = (v - i_mean[k]) * i_rstd[k];
+                    if (a.mask) v *= a.mask[(size_t)row * a.K + k];
+                }
+            }
+            Xs[r * a.pitch_x + k] = v;
+        }
+        __syncthreads();
+        // ---- 3. dW[n][k] += sum_rows dz[row][n] * xin[row][k]; wave owns tiles t = wv + 4 i ----
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int t = wv + 4 * i;
+            if (t < NT * KT) {
+                const int tn = t / KT, tk = t - tn * KT;
+                const float* ga = Gs + (lane >> 4) * a.pitch_g + tn * 16 + (lane & 15);
+                const float* xb = Xs + (lane >> 4) * a.pitch_x + tk * 16 + (lane & 15);
+#pragma unroll
+                for (int r4 = 0; r4 < 16; r4 += 4)
+                    wacc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[r4 * a.pitch_g], xb[r4 * a.pitch_x], wacc[i], 0, 0, 0);
+            }
+        }
+        // ---- 4. dx[row][k] = (sum_n dz[row][n] W[n][k]) * mask ; partial sums for the input's BN ----
+        if (a.dx != nullptr) {
+#pragma unroll
+            for (int i = 0; i < KT4; ++i) {
+                const int tk = wv + 4 * i;
+                if (tk < KT) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    const int kcol = tk * 16 + (lane & 15);
+                    const float* ga = Gs + (lane & 15) * a.pitch_g + (lane >> 4);
+                    const bool kok = kcol < a.K;
+                    for (int nn = 0; nn < N16; nn += 4) {
+                        const int n = nn + (lane >> 4);
+                        const float b = (kok && n < a.N) ? a.w[(size_t)n * a.K + kcol] : 0.f;
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[nn], b, acc, 0, 0, 0);
+                    }
+                    if (kok) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int row = row0 + (lane >> 4) * 4 + j;
+                            if (row < a.B) {
+                                const size_t o = (size_t)row * a.K + kcol;
+                                float d = acc[j];
+                                if (a.in_kind != RAAE_IN_NONE && a.mask) d *= a.mask[o];
+                                a.dx[o] = d;
+                                if (a.dx_partials != nullptr) {
+                                    const float y = (prelu(a.x[o], i_slope[kcol]) - i_mean[kcol]) * i_rstd[kcol];
+                                    dxs[i] += (double)d;
+                                    dxq[i] += (double)d * (double)y;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- write this workgroup's slabs ----
+    const size_t slab = (size_t)blockIdx.x * (size_t)a.slab_stride;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int t = wv + 4 * i;
+        if (t < NT * KT) {
+            const int tn = t / KT, tk = t - tn * KT;
+            const int k = tk * 16 + (lane & 15);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = tn * 16 + (lane >> 4) * 4 + j;
+                if (n < a.N && k < a.K) a.dw[slab + (size_t)n * a.K + k] = wacc[i][j];
+            }
+        }
+    }
+    // db / dslope: combine the row-phase copies of each column in fixed order
+    if (wideN) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int n = tid + h * 256;
+            if (n < a.N) {
+                a.db[slab + n] = db_acc[h];
+                if (a.dslope != nullptr) a.dslope[slab + n] = ds_acc[h];
+            }
+        }
+    } else {
+        red[tid] = db_acc[0];
+        red[256 + tid] = ds_acc[0];
+        __syncthreads();
+        if (tid < a.N) {
+            a.db[slab + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+            if (a.dslope != nullptr)
+                a.dslope[slab + tid] = (red[256 + tid] + red[320 + tid]) + (red[384 + tid] + red[448 + tid]);
+        }
+    }
+    if (a.dx != nullptr && a.dx_partials != nullptr) {
+#pragma unroll
+        for (int i = 0; i < KT4; ++i) {
+            const int tk = wv + 4 * i;
+            double s = dxs[i], q = dxq[i];
+            s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);
+            s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
+            const int kcol = tk * 16 + (lane & 15);
+            if (tk < KT && lane < 16 && kcol < a.K) {
+                double* p = a.dx_partials + ((size_t)blockIdx.x * a.K + kcol) * 2;
+                p[0] = s; p[1] = q;
+            }
+        }
+    }
+}
+
+int pick_grid(int B) {
+    const int ntiles = (B + 15) / 16;
+    return ntiles < 256 ? ntiles : 256;
+}
+
+}  // namespace
+
+extern "C" int raae_dense_fwd(const float* x, int B, int K, int in_kind, const float* slope, const raae_bn_t* bn,
+                              const float* mask, const float* w, const float* bias, int N, float* z, int out_kind,
+                              const float* out_slope, double* out_partials, int* out_nparts, void* stream) {
+    RAAE_CHECK_ARG(x && w && bias && z && B > 0 && K > 0 && N > 0 && K <= 4096);
+    RAAE_CHECK_ARG(in_kind >= 0 && in_kind <= 2 && out_kind >= 0 && out_kind <= 4);
+    RAAE_CHECK_ARG(in_kind == RAAE_IN_NONE || slope);
+    RAAE_CHECK_ARG(in_kind != RAAE_IN_PRELU_BN_DROP || (bn && (bn->partials || (bn->running_mean && bn->running_var))));
+    RAAE_CHECK_ARG(!(out_kind == RAAE_OUT_STATS_PRELU) || out_slope);
+    RAAE_CHECK_ARG(!(out_kind == RAAE_OUT_STATS_PRELU || out_kind == RAAE_OUT_STATS_RAW) || out_partials);
+    DenseFwdArgs a;
+    a.x = x; a.B = B; a.K = K; a.in_kind = in_kind; a.slope = slope; a.mask = mask;
+    if (bn) a.bn = *bn; else { raae_bn_t z0 = {}; a.bn = z0; }
+    RAAE_CHECK_ARG(a.bn.nparts >= 0 && a.bn.nparts <= RAAE_MAX_PARTS);
+    a.w = w; a.bias = bias; a.N = N; a.z = z; a.out_kind = out_kind; a.out_slope = out_slope;
+    a.out_partials = out_partials;
+    const int K4 = (K + 3) & ~3;
+    a.KC = K4 < 256 ? K4 : 256;
+    a.pitch = a.KC + 2;
+    a.resident = (K4 <= 256) ? 1 : 0;
+    const size_t lds = sizeof(float) * (3 * (size_t)K4 + 80 * (size_t)a.pitch);
+    RAAE_CHECK_ARG(lds <= 160 * 1024);
+    dim3 grid(pick_grid(B), (N + 63) / 64);
+    if (out_nparts) *out_nparts = (int)grid.x;
+    hipLaunchKernelGGL(dense_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
+    RAAE_LAUNCH_RET();
+}
+
+extern "C" int raae_dense_bwd(const float* g, int g_kind, const double* g_partials, int g_nparts, const float* zout,
+                              const float* out_slope, const raae_bn_t* out_bn, int B, int N,
+                              const float* x, int K, int in_kind, const float* slope, const raae_bn_t* bn,
+                              const float* mask, const float* w,
+                              float* dw, float* db, float* dslope, long slab_stride, int* nslab,
+                              float* dx, double* dx_partials, void* stream) {
+    RAAE_CHECK_ARG(g && x && w && dw && db && B > 0 && N > 0 && K > 0 && N <= 512 && K <= 512);
+    RAAE_CHECK_ARG(g_kind >= 0 && g_kind <= 4 && in_kind >= 0 && in_kind <= 2);
+    RAAE_CHECK_ARG(g_kind == RAAE_G_DIRECT || zout);
+    RAAE_CHECK_ARG(!(g_kind == RAAE_G_PRELU_BN) || (g_partials && out_bn && out_slope && g_nparts > 0 && g_nparts <= RAAE_MAX_PARTS));
+    RAAE_CHECK_ARG(!(g_kind == RAAE_G_PRELU) || out_slope);
+    RAAE_CHECK_ARG(in_kind == RAAE_IN_NONE || slope);
+    RAAE_CHECK_ARG(in_kind != RAAE_IN_PRELU_BN_DROP || bn);
+    RAAE_CHECK_ARG(!(dx && in_kind == RAAE_IN_PRELU_BN_DROP) || dx_partials);
+    DenseBwdArgs a;
+    a.g = g; a.g_kind = g_kind; a.g_partials = g_partials; a.g_nparts = g_nparts; a.zout = zout;
+    a.out_slope = out_slope;
+    raae_bn_t z0 = {};
+    a.out_bn = out_bn ? *out_bn : z0;
+    a.B = B; a.N = N; a.x = x; a.K = K; a.in_kind = in_kind; a.slope = slope;
+    a.bn = bn ? *bn : z0;
+    RAAE_CHECK_ARG(a.bn.nparts <= RAAE_MAX_PARTS && a.out_bn.nparts <= RAAE_MAX_PARTS);
+    a.mask = mask; a.w = w; a.dw = dw; a.db = db; a.dslope = dslope; a.slab_stride = slab_stride;
+    a.dx = dx; a.dx_partials = (in_kind == RAAE_IN_PRELU_BN_DROP) ? dx_partials : nullptr;
+    const int N16 = (N + 15) & ~15, K16 = (K + 15) & ~15;
+    a.pitch_g = N16 + 2; a.pitch_x = K16 + 2;
+    const int tiles = (N16 / 16) * (K16 / 16);
+    const int tpw = (tiles + 3) / 4, kt4 = (K16 / 16 + 3) / 4;
+    const size_t lds = sizeof(float) * (5 * (size_t)N16 + 3 * (size_t)K16 + 16 * (size_t)(a.pitch_g + a.pitch_x) + 512);
+    RAAE_CHECK_ARG(lds <= 160 * 1024);
+    // cap the number of slabs: each slab is N*K floats that the Adam kernel re-reads
+    int gx = pick_grid(B);
+    if ((long)N * K >= 8192 && gx > 64) gx = 64;
+    if (nslab) *nslab = gx;
+    dim3 grid(gx), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const bool need_dx = dx != nullptr;
+#define RAAE_BWD(TPW_, KT4_) hipLaunchKernelGGL((dense_bwd_kernel<TPW_, KT4_>), grid, block, lds, st, a)
+    if (tpw <= 1 && kt4 <= 1) RAAE_BWD(1, 1);
+    else if (tpw <= 4 && kt4 <= 1) RAAE_BWD(4, 1);
+    else if (tpw <= 16 && (kt4 <= 1 || !need_dx)) RAAE_BWD(16, 1);
+    else if (tpw <= 16 && kt4 <= 4) RAAE_BWD(16, 4);
+    else if (tpw <= 32 && (kt4 <= 1 || !need_dx)) RAAE_BWD(32, 1);
+    else if (tpw <= 32 && kt4 <= 8) RAAE_BWD(32, 8);
+    else return RAAE_EINVAL;
+#undef RAAE_BWD
+    RAAE_LAUNCH_RET();
+}

@@ -1,0 +1,442 @@
+// Loss kernels (forward + closed-form gradient in one pass each) and the encoder's
+// final BatchNorm.  Each replaces an ATen chain plus its autograd backward in
+// reference sc/utils/functions.py (cited per kernel).
+#include "raae_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ style BatchNorm
+// styles = BN(z) for z [B][C] (C = nstyle <= 64).  grid-stride over rows.
+__global__ __launch_bounds__(256) void style_bn_fwd_kernel(const float* z, int B, int C, raae_bn_t bn, float* out) {
+    __shared__ float s_mean[64], s_rstd[64];
+    raae::bn_prologue(bn, C, s_mean, s_rstd, blockIdx.x == 0);
+    const long n = (long)B * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        out[i] = (z[i] - s_mean[c]) * s_rstd[c];
+    }
+}
+
+// dz = rstd * (g - mean(g) - y * mean(g*y)), g = scale * dstyles.  Single workgroup: the
+// column sums over the whole batch are formed in fixed order (deterministic).
+__global__ __launch_bounds__(1024) void style_bn_bwd_kernel(const float* dy, const float* y, int B, int C,
+                                                            raae_bn_t bn, float scale, float* dz) {
+    __shared__ float s_mean[64], s_rstd[64];
+    __shared__ double s_s[64], s_q[64];
+    __shared__ double red[2][1024];
+    raae::bn_prologue(bn, C, s_mean, s_rstd, false);
+    // thread -> column c = tid % Cp, row phase = tid / Cp
+    const int tid = threadIdx.x;
+    const int nphase = 1024 / C;
+    const int c = tid % C, ph = tid / C;
+    double s = 0.0, q = 0.0;
+    if (ph < nphase) {
+        for (int r = ph; r < B; r += nphase) {
+            const float g = scale * dy[(size_t)r * C + c];
+            s += (double)g;
+            q += (double)g * (double)y[(size_t)r * C + c];
+        }
+    }
+    red[0][tid] = s; red[1][tid] = q;
+    __syncthreads();
+    if (tid < C) {
+        double ts = 0.0, tq = 0.0;
+        for (int p = 0; p < nphase; ++p) { ts += red[0][p * C + tid]; tq += red[1][p * C + tid]; }
+        s_s[tid] = ts / (double)B; s_q[tid] = tq / (double)B;
+    }
+    __syncthreads();
+    if (ph < nphase) {
+        const float m1 = (float)s_s[c], m2 = (float)s_q[c], rs = s_rstd[c];
+        for (int r = ph; r < B; r += nphase) {
+            const size_t o = (size_t)r * C + c;
+            dz[o] = rs * (scale * dy[o] - m1 - y[o] * m2);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ rank ("Kendall") loss
+// functions.py:37-79.  One pass over the B^2 pairs; per (i,k): g+ = sum_{j: p>0} s, g- = sum_{j: p<0} s;
+// per k: n+, n-, S+ = sum_{p>0} p, S- = sum_{p<0} p.  Thread owns one row i for ALL k (n_aux <= 16)
+// and streams the j rows through LDS tiles; counts are integers (exact), sums fp32 per thread,
+// double across threads.
+#define RANK_MAXK 16
+#define RANK_TJ 256
+struct RankWork {   // per-workgroup partial: [k]{n_pos, n_neg} ints and {S_pos, S_neg} doubles
+    long long n_pos[RANK_MAXK], n_neg[RANK_MAXK];
+    double s_pos[RANK_MAXK], s_neg[RANK_MAXK];
+};
+
+template <int KA>
+__global__ __launch_bounds__(256) void rank_pairs_kernel(const float* d, int ldd, const float* z, int ldz, int B,
+                                                         RankWork* part, float* gpos, float* gneg) {
+    __shared__ float sd[RANK_TJ * KA], sz[RANK_TJ * KA];
+    __shared__ double shd[16];
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * 256 + tid;
+    float di[KA], zi[KA], gp[KA], gn[KA], sp[KA], sn[KA];
+    int np[KA], nn[KA];
+#pragma unroll
+    for (int k = 0; k < KA; ++k) {
+        di[k] = (i < B) ? d[(size_t)i * ldd + k] : 0.f;
+        zi[k] = (i < B) ? z[(size_t)i * ldz + k] : 0.f;
+        gp[k] = gn[k] = sp[k] = sn[k] = 0.f; np[k] = nn[k] = 0;
+    }
+    for (int j0 = 0; j0 < B; j0 += RANK_TJ) {
+        const int nj = min(RANK_TJ, B - j0);
+        __syncthreads();
+        for (int idx = tid; idx < nj * KA; idx += 256) {
+            const int jj = idx / KA, k = idx - jj * KA;
+            sd[idx] = d[(size_t)(j0 + jj) * ldd + k];
+            sz[idx] = z[(size_t)(j0 + jj) * ldz + k];
+        }
+        __syncthreads();
+        if (i < B) {
+            for (int jj = 0; jj < nj; ++jj) {
+#pragma unroll
+                for (int k = 0; k < KA; ++k) {
+                    const float dd = di[k] - sd[jj * KA + k];
+                    const float s = dd > 0.f ? 1.f : (dd < 0.f ? -1.f : 0.f);
+                    const float p = (zi[k] - sz[jj * KA + k]) * s;
+                    if (p > 0.f) { np[k]++; sp[k] += p; gp[k] += s; }
+                    else if (p < 0.f) { nn[k]++; sn[k] += p; gn[k] += s; }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KA; ++k) {
+        if (i < B) { gpos[(size_t)i * KA + k] = gp[k]; gneg[(size_t)i * KA + k] = gn[k]; }
+        const double a = raae::block_sum((double)sp[k], shd);
+        const double b = raae::block_sum((double)sn[k], shd);
+        const double c = raae::block_sum((double)np[k], shd);
+        const double e = raae::block_sum((double)nn[k], shd);
+        if (tid == 0) {
+            part[blockIdx.x].s_pos[k] = a; part[blockIdx.x].s_neg[k] = b;
+            part[blockIdx.x].n_pos[k] = (long long)(c + 0.5); part[blockIdx.x].n_neg[k] = (long long)(e + 0.5);
+        }
+    }
+}
+
+// finalize: c_k, loss, dz[i][k] = -(2/norm)(c_k g+ + g-).  grid-stride; every workgroup re-derives c_k.
+__global__ __launch_bounds__(256) void rank_finalize_kernel(const RankWork* part, int nparts, int B, int KA, int activate,
+                                                            const float* gpos, const float* gneg, float* loss,
+                                                            float* dz, int ldz) {
+    __shared__ float s_c[RANK_MAXK];
+    __shared__ double s_loss[RANK_MAXK];
+    const int tid = threadIdx.x;
+    const double norm = ((double)B * (double)B - (double)B) * (double)KA;
+    if (tid < KA) {
+        long long np = 0, nn = 0; double sp = 0.0, sn = 0.0;
+        for (int p = 0; p < nparts; ++p) {
+            np += part[p].n_pos[tid]; nn += part[p].n_neg[tid];
+            sp += part[p].s_pos[tid]; sn += part[p].s_neg[tid];
+        }
+        double c = 1.0;
+        if (activate) {
+            const double n_same = (double)(np > 1 ? np : 1), n_opp = (double)(nn > 1 ? nn : 1);
+            c = n_opp / (n_same > n_opp ? n_same : n_opp);
+        }
+        s_c[tid] = (float)c;
+        s_loss[tid] = c * sp + sn;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && tid == 0) {
+        double t = 0.0;
+        for (int k = 0; k < KA; ++k) t += s_loss[k];
+        loss[0] = (float)(-t / norm);
+    }
+    if (dz != nullptr) {
+        const float f = (float)(-2.0 / norm);
+        const long n = (long)B * ldz;
+        for (long idx = (long)blockIdx.x * 256 + tid; idx < n; idx += (long)gridDim.x * 256) {
+            const int i = (int)(idx / ldz), k = (int)(idx - (long)i * ldz);
+            dz[idx] = (k < KA) ? f * (s_c[k] * gpos[(size_t)i * KA + k] + gneg[(size_t)i * KA + k]) : 0.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ reconstruction loss
+// functions.py:81-107.  One wave per row; L <= 1024.
+__global__ __launch_bounds__(256) void recon_kernel(const float* x, const float* y, int B, int L, int scale,
+                                                    double* partial, float* dy) {
+    __shared__ double shd[16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double acc = 0.0;
+    for (int row = blockIdx.x * 4 + wv; row < B; row += gridDim.x * 4) {
+        const float* xr = x + (size_t)row * L;
+        const float* yr = y + (size_t)row * L;
+        float c = 1.f, gscale = 0.f;
+        if (scale) {
+            float sx = 0.f, sy = 0.f;
+            for (int l = lane; l < L; l += 64) { sx += xr[l]; sy += yr[l]; }
+            sx = raae::wave_sum(sx); sy = raae::wave_sum(sy);
+            const float mx = sx / (float)L, my = sy / (float)L;
+            const float r = fabsf(my) / fabsf(mx);
+            c = fminf(fmaxf(r, 0.7f), 1.3f);
+            if (lane == 0) acc += 0.1 * (double)(r - 1.f) * (double)(r - 1.f) / (double)B;
+            const float sg = my > 0.f ? 1.f : (my < 0.f ? -1.f : 0.f);
+            gscale = 0.2f * (r - 1.f) * sg / (fabsf(mx) * (float)L * (float)B);
+        }
+        const float inv = 1.f / ((float)B * (float)L);
+        float se = 0.f;
+        for (int l = lane; l < L; l += 64) {
+            const float e = yr[l] - xr[l] * c;
+            se += e * e;
+            if (dy) dy[(size_t)row * L + l] = 2.f * e * inv + gscale;
+        }
+        se = raae::wave_sum(se);
+        if (lane == 0) acc += (double)se / ((double)B * (double)L);
+    }
+    const double t = raae::block_sum(acc, shd);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+// ------------------------------------------------------------------ smoothness loss
+// functions.py:194-212 + GaussianSmoothing (model.py:177-229).  One wave per row, row in LDS.
+// loss = mean((x - Gx)^2); dL/dx = (2/N) (e - G^T e), e = x - Gx, G = replicate-pad Gaussian.
+#define SM_MAXT 33
+struct Taps { float w[SM_MAXT]; int n; };
+
+__global__ __launch_bounds__(256) void smooth_kernel(const float* x, int B, int L, Taps tp, double* partial, float* dx) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [4 waves][2][L]
+    __shared__ double shd[16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* xs = smem + (size_t)wv * 2 * L;
+    float* es = xs + L;
+    const int half = (tp.n - 1) / 2;
+    double acc = 0.0;
+    const float inv = 1.f / ((float)B * (float)L);
+    for (int row = blockIdx.x * 4 + wv; row < B; row += gridDim.x * 4) {
+        const float* xr = x + (size_t)row * L;
+        for (int l = lane; l < L; l += 64) xs[l] = xr[l];
+        __builtin_amdgcn_wave_barrier();
+        float se = 0.f;
+        for (int l = lane; l < L; l += 64) {
+            float g = 0.f;
+            for (int t = 0; t < tp.n; ++t) {
+                int j = l + t - half;
+                j = j < 0 ? 0 : (j > L - 1 ? L - 1 : j);
+                g += tp.w[t] * xs[j];
+            }
+            const float e = xs[l] - g;
+            es[l] = e;
+            se += e * e;
+        }
+        se = raae::wave_sum(se);
+        if (lane == 0) acc += (double)se / ((double)B * (double)L);
+        __builtin_amdgcn_wave_barrier();
+        if (dx) {
+            // (G^T e)_j = sum over padded positions q = l + t - half that clamp to j
+            for (int j = lane; j < L; j += 64) {
+                float gt = 0.f;
+                // interior contribution: l = j - t + half, any l in [0, L)
+                for (int t = 0; t < tp.n; ++t) {
+                    const int l = j - t + half;
+                    if (l >= 0 && l < L) gt += tp.w[t] * es[l];
+                }
+                if (j == 0) {            // padded positions q < 0 clamp to 0: l + t - half < 0
+                    for (int l = 0; l < half && l < L; ++l)
+                        for (int t = 0; t < half - l; ++t) gt += tp.w[t] * es[l];
+                }
+                if (j == L - 1) {        // q > L-1: l + t - half > L-1
+                    for (int l = max(0, L - half); l < L; ++l)
+                        for (int t = L - l + half; t < tp.n; ++t) gt += tp.w[t] * es[l];
+                }
+                dx[(size_t)row * L + j] = 2.f * inv * (es[j] - gt);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    const double t = raae::block_sum(acc, shd);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+// ------------------------------------------------------------------ MSE (mutual-info loss)
+__global__ __launch_bounds__(256) void mse_kernel(const float* a, const float* b, long n, double* partial, float* da) {
+    __shared__ double shd[16];
+    double acc = 0.0;
+    const float inv = 1.f / (float)n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float e = a[i] - b[i];
+        acc += (double)e * (double)e;
+        if (da) da[i] = 2.f * e * inv;
+    }
+    const double t = raae::block_sum(acc, shd);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t / (double)n;
+}
+
+// ------------------------------------------------------------------ BCE-with-logits pair
+// functions.py:119-130: mean_i softplus(-o_i) over real + mean_i softplus(o_i) over fake.
+__device__ __forceinline__ double softplus_d(double x) { return x > 0.0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
+
+__global__ __launch_bounds__(1024) void bce_pair_kernel(const float* o, int n_real, int n_fake, float* loss, float* d) {
+    __shared__ double shd[16];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n_real + n_fake; i += 1024) {
+        const float v = o[i];
+        const float sg = 1.f / (1.f + expf(-v));
+        if (i < n_real) { acc += softplus_d(-(double)v) / (double)n_real; if (d) d[i] = (sg - 1.f) / (float)n_real; }
+        else { acc += softplus_d((double)v) / (double)n_fake; if (d) d[i] = sg / (float)n_fake; }
+    }
+    const double t = raae::block_sum(acc, shd);
+    if (threadIdx.x == 0) loss[0] = (float)t;
+}
+
+__global__ void disc_input_kernel(const float* z_real, const float* styles, const float* noise, float sigma,
+                                  int n_real, int n_fake, int C, float* out) {
+    const long n = (long)(n_real + n_fake) * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long split = (long)n_real * C;
+        float v = i < split ? z_real[i] : styles[i - split];
+        if (noise) v += sigma * noise[i];
+        out[i] = v;
+    }
+}
+
+__global__ void scale_by_dev_kernel(const float* src, const float* dev_scale, float sign, long n, float* dst) {
+    const float s = sign * dev_scale[0];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = s * src[i];
+}
+
+__global__ void loss_finalize_kernel(const double* partial, int n, float scale, float* out, int slot, int acc_slot) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < n; ++i) t += partial[i];
+        const float v = (float)(t * (double)scale);
+        out[slot] = v;
+        if (acc_slot >= 0) out[acc_slot] += v;
+    }
+}
+
+__global__ void gather_batch_kernel(const float* spec, const float* aux, const long* idx_all, const int* cursor,
+                                    const float* noise, float spec_noise, int B, int L, int n_aux, float* spec_out,
+                                    float* aux_out) {
+    // the step tick has already advanced the cursor past this batch: rows [cursor-B, cursor)
+    const long* idx = idx_all + (cursor ? (cursor[0] - B) : 0);
+    const long n = (long)B * L;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int b = (int)(i / L), l = (int)(i - (long)b * L);
+        float v = spec[(size_t)idx[b] * L + l];
+        if (noise) v += noise[i] * spec_noise;
+        spec_out[i] = v;
+    }
+    const long na = (long)B * n_aux;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < na; i += (long)gridDim.x * 256) {
+        const int b = (int)(i / n_aux), k = (int)(i - (long)b * n_aux);
+        aux_out[i] = aux[(size_t)idx[b] * n_aux + k];
+    }
+}
+
+int grid_for(long n, int per_block, int cap) {
+    long g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    return (int)(g < cap ? g : cap);
+}
+
+}  // namespace
+
+extern "C" int raae_style_bn_fwd(const float* z, int B, int C, const raae_bn_t* bn, float* styles, void* stream) {
+    RAAE_CHECK_ARG(z && bn && styles && B > 0 && C > 0 && C <= 64 && bn->nparts <= RAAE_MAX_PARTS);
+    hipLaunchKernelGGL(style_bn_fwd_kernel, dim3(grid_for((long)B * C, 256, 256)), dim3(256), 0, (hipStream_t)stream,
+                       z, B, C, *bn, styles);
+    RAAE_LAUNCH_RET();
+}
+
+extern "C" int raae_style_bn_bwd(const float* dstyles, const float* styles, int B, int C, const raae_bn_t* bn,
+                                 float scale, float* dz, void* stream) {
+    RAAE_CHECK_ARG(dstyles && styles && bn && dz && B > 0 && C > 0 && C <= 64 && bn->nparts <= RAAE_MAX_PARTS);
+    hipLaunchKernelGGL(style_bn_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dstyles, styles, B, C, *bn,
+                       scale, dz);
+    RAAE_LAUNCH_RET();
+}
+
+extern "C" long raae_rank_loss_work_bytes(int B, int n_aux) {
+    const long nb = (B + 255) / 256;
+    return nb * (long)sizeof(RankWork) + 2L * B * n_aux * (long)sizeof(float) + 256;
+}
+
+extern "C" int raae_rank_loss_fwd_bwd(const float* d, int ldd, const float* z, int ldz, int B, int n_aux, int activate,
+                                      void* work, float* loss, float* dz, void* stream) {
+    RAAE_CHECK_ARG(d && z && work && loss && B > 1 && n_aux >= 1 && n_aux <= RANK_MAXK && ldd >= n_aux && ldz >= n_aux);
+    const int nb = (B + 255) / 256;
+    RankWork* part = (RankWork*)work;
+    float* gpos = (float*)((char*)work + (((size_t)nb * sizeof(RankWork) + 255) & ~(size_t)255));
+    float* gneg = gpos + (size_t)B * n_aux;
+    hipStream_t st = (hipStream_t)stream;
+#define RANK_CASE(KA) case KA: hipLaunchKernelGGL((rank_pairs_kernel<KA>), dim3(nb), dim3(256), 0, st, d, ldd, z, ldz, B, part, gpos, gneg); break;
+    switch (n_aux) {
+        RANK_CASE(1) RANK_CASE(2) RANK_CASE(3) RANK_CASE(4) RANK_CASE(5) RANK_CASE(6) RANK_CASE(7) RANK_CASE(8)
+        RANK_CASE(9) RANK_CASE(10) RANK_CASE(11) RANK_CASE(12) RANK_CASE(13) RANK_CASE(14) RANK_CASE(15) RANK_CASE(16)
+        default: return RAAE_EINVAL;
+    }
+#undef RANK_CASE
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    const int gf = dz ? grid_for((long)B * ldz, 256, 256) : 1;
+    hipLaunchKernelGGL(rank_finalize_kernel, dim3(gf), dim3(256), 0, st, part, nb, B, n_aux, activate, gpos, gneg, loss, dz, ldz);
+    RAAE_LAUNCH_RET();
+}
+
+extern "C" int raae_recon_loss_fwd_bwd(const float* spec_in, const float* spec_out, int B, int L, int scale,
+                                       double* partial, int* nparts, float* dout, void* stream) {
+    RAAE_CHECK_ARG(spec_in && spec_out && partial && B > 0 && L > 0);
+    const int g = grid_for(B, 4, RAAE_MAX_PARTS);
+    if (nparts) *nparts = g;
+    hipLaunchKernelGGL(recon_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, spec_in, spec_out, B, L, scale, partial, dout);
+    RAAE_LAUNCH_RET();
+}
+
+extern "C" int raae_smooth_loss_fwd_bwd(const float* x, int B, int L, const float* taps, int ntaps,
+                                        double* partial, int* nparts, float* dx, void* stream) {
+    RAAE_CHECK_ARG(x && taps && partial && B > 0 && L > 1 && ntaps >= 1 && ntaps <= SM_MAXT && (ntaps & 1) && L <= 4096);
+    Taps tp; tp.n = ntaps;
+    for (int i = 0; i < ntaps; ++i) tp.w[i] = taps[i];   // `taps` is a HOST pointer (17 floats)
+    const int g = grid_for(B, 4, RAAE_MAX_PARTS);
+    if (nparts) *nparts = g;
+    hipLaunchKernelGGL(smooth_kernel, dim3(g), dim3(256), sizeof(float) * 8 * (size_t)L, (hipStream_t)stream, x, B, L, tp, partial, dx);
+    RAAE_LAUNCH_RET();
+}
+
+extern "C" int raae_mse_fwd_bwd(const float* a, const float* b, long n, double* partial, int* nparts, float* da, void* stream) {
+    RAAE_CHECK_ARG(a && b && partial && n > 0);
+    const int g = grid_for(n, 1024, RAAE_MAX_PARTS);
+    if (nparts) *nparts = g;
+    hipLaunchKernelGGL(mse_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, a, b, n, partial, da);
+    RAAE_LAUNCH_RET();
+}
+
+extern "C" int raae_bce_pair_fwd_bwd(const float* logits, int n_real, int n_fake, float* loss, float* dlogits, void* stream) {
+    RAAE_CHECK_ARG(logits && loss && n_real > 0 && n_fake > 0);
+    hipLaunchKernelGGL(bce_pair_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, n_real, n_fake, loss, dlogits);
+    RAAE_LAUNCH_RET();
+}
+
+extern "C" int raae_disc_input(const float* z_real, const float* styles, const float* noise, float sigma,
+                               int n_real, int n_fake, int C, float* out, void* stream) {
+    RAAE_CHECK_ARG(z_real && styles && out && n_real > 0 && n_fake > 0 && C > 0);
+    const long n = (long)(n_real + n_fake) * C;
+    hipLaunchKernelGGL(disc_input_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream,
+                       z_real, styles, noise, sigma, n_real, n_fake, C, out);
+    RAAE_LAUNCH_RET();
+}
+
+extern "C" int raae_scale_by_dev(const float* src, const float* dev_scale, float sign, long n, float* dst, void* stream) {
+    RAAE_CHECK_ARG(src && dev_scale && dst && n > 0);
+    hipLaunchKernelGGL(scale_by_dev_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, src, dev_scale, sign, n, dst);
+    RAAE_LAUNCH_RET();
+}
+
+extern "C" int raae_loss_finalize(const double* partial, int n, float scale, float* out, int slot, int acc_slot, void* stream) {
+    RAAE_CHECK_ARG(partial && out && n > 0 && slot >= 0);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, n, scale, out, slot, acc_slot);
+    RAAE_LAUNCH_RET();
+}
+
+extern "C" int raae_gather_batch(const float* spec, const float* aux, const long* idx, const int* cursor,
+                                 const float* noise, float spec_noise, int B, int L, int n_aux, float* spec_out,
+                                 float* aux_out, void* stream) {
+    RAAE_CHECK_ARG(spec && aux && idx && spec_out && aux_out && B > 0 && L > 0 && n_aux > 0);
+    hipLaunchKernelGGL(gather_batch_kernel, dim3(grid_for((long)B * L, 256, 2048)), dim3(256), 0, (hipStream_t)stream,
+                       spec, aux, idx, cursor, noise, spec_noise, B, L, n_aux, spec_out, aux_out);
+    RAAE_LAUNCH_RET();
+}

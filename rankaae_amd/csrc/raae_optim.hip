@@ -1,0 +1,185 @@
+// Fused multi-tensor Adam/AdamW over the flat parameter arena, the per-step tick,
+// the Philox random tape, and HIP stream/graph/event plumbing.
+#include "raae_common.h"
+#include <string.h>
+
+namespace {
+
+// torch.optim.Adam / AdamW single-tensor update (torch/optim/adam.py::_single_tensor_adam),
+// operation order mirrored in fp32; scalars formed in double like Python floats.
+// Gradient of element i = fixed-order sum of seg_nslab[i/64] slabs; 0 slabs => parameter is
+// skipped (the reference skips params whose .grad is None, trainer.py:318-321).
+__global__ __launch_bounds__(256) void adam_kernel(float* p, float* m, float* v, const float* g_slabs, long slab_stride,
+                                                   const unsigned char* seg_nslab, long n, const double* hyper,
+                                                   const int* step, int decoupled) {
+    __shared__ float s_sc[8];
+    if (threadIdx.x == 0) {
+        const double lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
+        const double t = (double)step[0];
+        const double bc1 = 1.0 - pow(b1, t), bc2 = 1.0 - pow(b2, t);
+        s_sc[0] = (float)(1.0 - lr * wd);      // AdamW decay factor
+        s_sc[1] = (float)(1.0 - b1);           // lerp weight
+        s_sc[2] = (float)b2;
+        s_sc[3] = (float)(1.0 - b2);
+        s_sc[4] = (float)(-(lr / bc1));        // -step_size
+        s_sc[5] = (float)sqrt(bc2);
+        s_sc[6] = (float)eps;
+        s_sc[7] = (float)wd;
+    }
+    __syncthreads();
+    const float decay = s_sc[0], w1 = s_sc[1], b2f = s_sc[2], omb2 = s_sc[3], nstep = s_sc[4], bc2s = s_sc[5],
+                epsf = s_sc[6], wdf = s_sc[7];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int ns = seg_nslab[i >> 6];
+        if (ns == 0) continue;
+        float g = g_slabs[i];
+        for (int s = 1; s < ns; ++s) g += g_slabs[(size_t)s * slab_stride + i];
+        float pv = p[i];
+        if (decoupled) pv = pv * decay; else if (wdf != 0.f) g = g + wdf * pv;
+        float mv = m[i], vv = v[i];
+        mv = mv + w1 * (g - mv);
+        vv = vv * b2f;
+        vv = vv + (omb2 * g) * g;
+        const float denom = sqrtf(vv) / bc2s + epsf;
+        pv = pv + (nstep * mv) / denom;
+        p[i] = pv; m[i] = mv; v[i] = vv;
+    }
+}
+
+__global__ void tick_kernel(int* steps, int n, unsigned mask, unsigned long long* rng_counter, int* cursor,
+                            int cursor_inc) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int i = 0; i < n; ++i) if (mask & (1u << i)) steps[i] += 1;
+        if (rng_counter) rng_counter[0] += 1ull;
+        if (cursor) cursor[0] += cursor_inc;
+    }
+}
+
+// ---- Philox4x32-10 (Salmon et al. 2011) ----
+__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+__device__ __forceinline__ void philox(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c[0], c[1], c[2], c[3], k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+// tape segments start at multiples of 4 floats; thread i fills floats [4i, 4i+4).
+__global__ __launch_bounds__(256) void rng_fill_kernel(float* tape, const int* seg_desc, const float* seg_scale, int nseg,
+                                                       long total, unsigned long long seed,
+                                                       const unsigned long long* counter) {
+    const unsigned long long ctr = counter ? counter[0] : 0ull;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q * 4 < total; q += (long)gridDim.x * 256) {
+        const long e0 = q * 4;
+        int lo = 0, hi = nseg - 1;
+        while (lo < hi) {                       // last segment whose offset <= e0
+            const int mid = (lo + hi + 1) >> 1;
+            if ((long)seg_desc[mid * 4] <= e0) lo = mid; else hi = mid - 1;
+        }
+        const int kind = seg_desc[lo * 4 + 2];
+        const long send = (long)seg_desc[lo * 4] + seg_desc[lo * 4 + 1];
+        uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)ctr, (uint32_t)(ctr >> 32)};
+        philox(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        float o[4];
+        if (kind == 0) {
+            const float r0 = sqrtf(-2.f * logf(u01(c[0]))), r1 = sqrtf(-2.f * logf(u01(c[2])));
+            const float a0 = 6.283185307179586f * u01(c[1]), a1 = 6.283185307179586f * u01(c[3]);
+            o[0] = r0 * cosf(a0); o[1] = r0 * sinf(a0); o[2] = r1 * cosf(a1); o[3] = r1 * sinf(a1);
+        } else {
+            const float keep = seg_scale[lo], inv = 1.f / keep;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = u01(c[j]) < keep ? inv : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (e0 + j < send && e0 + j < total) tape[e0 + j] = o[j];
+    }
+}
+
+}  // namespace
+
+extern "C" int raae_adam_step(float* p, float* m, float* v, const float* g_slabs, long slab_stride,
+                              const unsigned char* seg_nslab, long n, const double* hyper, const int* step,
+                              int decoupled, void* stream) {
+    RAAE_CHECK_ARG(p && m && v && g_slabs && seg_nslab && hyper && step && n > 0 && (n % 64) == 0);
+    long g = (n + 1023) / 1024;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(adam_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, p, m, v, g_slabs, slab_stride,
+                       seg_nslab, n, hyper, step, decoupled);
+    RAAE_LAUNCH_RET();
+}
+
+extern "C" int raae_step_tick(int* steps, int n, unsigned mask, unsigned long long* rng_counter, int* cursor,
+                              int cursor_inc, void* stream) {
+    RAAE_CHECK_ARG(steps && n >= 0 && n <= 32);
+    hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, steps, n, mask, rng_counter, cursor, cursor_inc);
+    RAAE_LAUNCH_RET();
+}
+
+extern "C" int raae_rng_fill(float* tape, const int* seg_desc, const float* seg_scale, int nseg, long total,
+                             unsigned long long seed, const unsigned long long* counter, void* stream) {
+    RAAE_CHECK_ARG(tape && seg_desc && seg_scale && nseg > 0 && total > 0);
+    long g = (total / 4 + 255) / 256;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(rng_fill_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, tape, seg_desc, seg_scale, nseg,
+                       total, seed, counter);
+    RAAE_LAUNCH_RET();
+}
+
+// ---------------------------------------------------------------- runtime plumbing
+extern "C" int raae_graph_begin(void* stream) {
+    return (int)hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal);
+}
+extern "C" int raae_graph_end(void* stream, void** graph_exec) {
+    RAAE_CHECK_ARG(graph_exec);
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamEndCapture((hipStream_t)stream, &graph);
+    if (e != hipSuccess) return (int)e;
+    hipGraphExec_t ex = nullptr;
+    e = hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e != hipSuccess) return (int)e;
+    *graph_exec = (void*)ex;
+    return 0;
+}
+extern "C" int raae_graph_launch(void* graph_exec, void* stream) {
+    return (int)hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream);
+}
+extern "C" int raae_graph_destroy(void* graph_exec) { return (int)hipGraphExecDestroy((hipGraphExec_t)graph_exec); }
+extern "C" int raae_event_create(void** ev) {
+    RAAE_CHECK_ARG(ev);
+    hipEvent_t e; hipError_t r = hipEventCreate(&e);
+    *ev = (void*)e; return (int)r;
+}
+extern "C" int raae_event_record(void* ev, void* stream) { return (int)hipEventRecord((hipEvent_t)ev, (hipStream_t)stream); }
+extern "C" int raae_event_elapsed_ms(void* start, void* stop, float* ms) {
+    RAAE_CHECK_ARG(ms);
+    hipError_t r = hipEventSynchronize((hipEvent_t)stop);
+    if (r != hipSuccess) return (int)r;
+    return (int)hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
+}
+extern "C" int raae_event_destroy(void* ev) { return (int)hipEventDestroy((hipEvent_t)ev); }
+extern "C" int raae_stream_sync(void* stream) { return (int)hipStreamSynchronize((hipStream_t)stream); }
+extern "C" const char* raae_error_string(int code) {
+    if (code == RAAE_EINVAL) return "raae: invalid argument (host-side shape validation failed; nothing launched)";
+    return hipGetErrorString((hipError_t)code);
+}
+extern "C" int raae_device_info(int* cu_count, int* lds_bytes, char* name, int name_len) {
+    hipDeviceProp_t prop; int dev = 0;
+    hipError_t r = hipGetDevice(&dev);
+    if (r != hipSuccess) return (int)r;
+    r = hipGetDeviceProperties(&prop, dev);
+    if (r != hipSuccess) return (int)r;
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (lds_bytes) *lds_bytes = (int)prop.sharedMemPerBlock;
+    if (name && name_len > 0) { strncpy(name, prop.gcnArchName, name_len - 1); name[name_len - 1] = 0; }
+    return 0;
+}
+extern "C" int raae_abi_version(void) { return 1; }

@@ -1,0 +1,182 @@
+"""Thin Python wrappers over the C ABI: torch tensors in (device memory + current stream
+only -- PyTorch is plumbing here), HIP kernels underneath.  No fallback paths.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import BnT, check
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t, dtype=torch.float32):
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return C.c_void_p(t)
+    assert t.is_cuda and t.is_contiguous(), "device, contiguous tensors only"
+    if dtype is not None:
+        assert t.dtype == dtype, (t.dtype, dtype)
+    return C.c_void_p(t.data_ptr())
+
+
+def make_bn(partials=None, nparts=0, count=0.0, running_mean=None, running_var=None, momentum=0.1, eps=1e-5,
+            update_running=False):
+    """Build a ``raae_bn_t``.  ``partials=None`` selects eval mode (running statistics)."""
+    bn = BnT()
+    bn.partials = partials.data_ptr() if partials is not None else None
+    bn.nparts = int(nparts)
+    bn.count = float(count)
+    bn.running_mean = running_mean.data_ptr() if running_mean is not None else None
+    bn.running_var = running_var.data_ptr() if running_var is not None else None
+    bn.momentum = float(momentum)
+    bn.eps = float(eps)
+    bn.update_running = 1 if update_running else 0
+    return bn
+
+
+def _bnp(bn):
+    return C.byref(bn) if bn is not None else None
+
+
+def dense_fwd(x, B, K, in_kind, slope, bn, mask, w, bias, N, z, out_kind, out_slope=None, out_partials=None):
+    n = C.c_int(0)
+    check(_lib.load().raae_dense_fwd(_ptr(x), B, K, in_kind, _ptr(slope), _bnp(bn), _ptr(mask), _ptr(w), _ptr(bias),
+                                     N, _ptr(z), out_kind, _ptr(out_slope), _ptr(out_partials, torch.float64),
+                                     C.byref(n), _stream()), "raae_dense_fwd")
+    return n.value
+
+
+def dense_bwd(g, g_kind, g_partials, g_nparts, zout, out_slope, out_bn, B, N, x, K, in_kind, slope, bn, mask, w,
+              dw, db, dslope, slab_stride, dx=None, dx_partials=None):
+    n = C.c_int(0)
+    check(_lib.load().raae_dense_bwd(_ptr(g), g_kind, _ptr(g_partials, torch.float64), g_nparts, _ptr(zout),
+                                     _ptr(out_slope), _bnp(out_bn), B, N, _ptr(x), K, in_kind, _ptr(slope), _bnp(bn),
+                                     _ptr(mask), _ptr(w), _ptr(dw), _ptr(db), _ptr(dslope), slab_stride, C.byref(n),
+                                     _ptr(dx), _ptr(dx_partials, torch.float64), _stream()), "raae_dense_bwd")
+    return n.value
+
+
+def style_bn_fwd(z, B, Cc, bn, styles):
+    check(_lib.load().raae_style_bn_fwd(_ptr(z), B, Cc, _bnp(bn), _ptr(styles), _stream()), "raae_style_bn_fwd")
+
+
+def style_bn_bwd(dstyles, styles, B, Cc, bn, dz, scale=1.0):
+    check(_lib.load().raae_style_bn_bwd(_ptr(dstyles), _ptr(styles), B, Cc, _bnp(bn), scale, _ptr(dz), _stream()),
+          "raae_style_bn_bwd")
+
+
+def rank_loss_work_bytes(B, n_aux):
+    return int(_lib.load().raae_rank_loss_work_bytes(B, n_aux))
+
+
+def rank_loss_fwd_bwd(d, ldd, z, ldz, B, n_aux, activate, work, loss, dz):
+    check(_lib.load().raae_rank_loss_fwd_bwd(_ptr(d), ldd, _ptr(z), ldz, B, n_aux, 1 if activate else 0,
+                                             _ptr(work, None), _ptr(loss), _ptr(dz), _stream()),
+          "raae_rank_loss_fwd_bwd")
+
+
+def recon_loss_fwd_bwd(spec_in, spec_out, B, L, scale, partial, dout):
+    n = C.c_int(0)
+    check(_lib.load().raae_recon_loss_fwd_bwd(_ptr(spec_in), _ptr(spec_out), B, L, 1 if scale else 0,
+                                              _ptr(partial, torch.float64), C.byref(n), _ptr(dout), _stream()),
+          "raae_recon_loss_fwd_bwd")
+    return n.value
+
+
+def smooth_loss_fwd_bwd(x, B, L, taps, partial, dx):
+    n = C.c_int(0)
+    arr = (C.c_float * len(taps))(*[float(t) for t in taps])
+    check(_lib.load().raae_smooth_loss_fwd_bwd(_ptr(x), B, L, arr, len(taps), _ptr(partial, torch.float64),
+                                               C.byref(n), _ptr(dx), _stream()), "raae_smooth_loss_fwd_bwd")
+    return n.value
+
+
+def mse_fwd_bwd(a, b, n_el, partial, da):
+    n = C.c_int(0)
+    check(_lib.load().raae_mse_fwd_bwd(_ptr(a), _ptr(b), n_el, _ptr(partial, torch.float64), C.byref(n), _ptr(da),
+                                       _stream()), "raae_mse_fwd_bwd")
+    return n.value
+
+
+def bce_pair_fwd_bwd(logits, n_real, n_fake, loss, dlogits):
+    check(_lib.load().raae_bce_pair_fwd_bwd(_ptr(logits), n_real, n_fake, _ptr(loss), _ptr(dlogits), _stream()),
+          "raae_bce_pair_fwd_bwd")
+
+
+def disc_input(z_real, styles, noise, sigma, n_real, n_fake, Cc, out):
+    check(_lib.load().raae_disc_input(_ptr(z_real), _ptr(styles), _ptr(noise), sigma, n_real, n_fake, Cc, _ptr(out),
+                                      _stream()), "raae_disc_input")
+
+
+def scale_by_dev(src, dev_scale, sign, n, dst):
+    check(_lib.load().raae_scale_by_dev(_ptr(src), _ptr(dev_scale), sign, n, _ptr(dst), _stream()),
+          "raae_scale_by_dev")
+
+
+def loss_finalize(partial, n, scale, out, slot, acc_slot=-1):
+    check(_lib.load().raae_loss_finalize(_ptr(partial, torch.float64), n, scale, _ptr(out), slot, acc_slot,
+                                         _stream()), "raae_loss_finalize")
+
+
+def gather_batch(spec, aux, idx, cursor, noise, spec_noise, B, L, n_aux, spec_out, aux_out):
+    check(_lib.load().raae_gather_batch(_ptr(spec), _ptr(aux), _ptr(idx, torch.int64), _ptr(cursor, torch.int32),
+                                        _ptr(noise), spec_noise, B, L, n_aux, _ptr(spec_out), _ptr(aux_out),
+                                        _stream()), "raae_gather_batch")
+
+
+def adam_step(p, m, v, g_slabs, slab_stride, seg_nslab, n, hyper, step, decoupled):
+    check(_lib.load().raae_adam_step(_ptr(p), _ptr(m), _ptr(v), _ptr(g_slabs), slab_stride,
+                                     _ptr(seg_nslab, torch.uint8), n, _ptr(hyper, torch.float64),
+                                     _ptr(step, torch.int32), 1 if decoupled else 0, _stream()), "raae_adam_step")
+
+
+def step_tick(steps, n, mask, rng_counter, cursor, cursor_inc):
+    check(_lib.load().raae_step_tick(_ptr(steps, torch.int32), n, mask, _ptr(rng_counter, torch.int64),
+                                     _ptr(cursor, torch.int32), cursor_inc, _stream()), "raae_step_tick")
+
+
+def rng_fill(tape, seg_desc, seg_scale, nseg, total, seed, counter):
+    check(_lib.load().raae_rng_fill(_ptr(tape), _ptr(seg_desc, torch.int32), _ptr(seg_scale), nseg, total,
+                                    C.c_ulonglong(seed), _ptr(counter, torch.int64), _stream()), "raae_rng_fill")
+
+
+class Graph:
+    """A captured HIP graph of one training step (hipStreamBeginCapture / hipGraphLaunch)."""
+
+    def __init__(self):
+        self.handle = C.c_void_p()
+
+    def begin(self):
+        check(_lib.load().raae_graph_begin(_stream()), "raae_graph_begin")
+
+    def end(self):
+        check(_lib.load().raae_graph_end(_stream(), C.byref(self.handle)), "raae_graph_end")
+
+    def launch(self):
+        check(_lib.load().raae_graph_launch(self.handle, _stream()), "raae_graph_launch")
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.load().raae_graph_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class Event:
+    def __init__(self):
+        self.h = C.c_void_p()
+        check(_lib.load().raae_event_create(C.byref(self.h)), "raae_event_create")
+
+    def record(self):
+        check(_lib.load().raae_event_record(self.h, _stream()), "raae_event_record")
+
+    def elapsed_ms(self, stop):
+        ms = C.c_float(0)
+        check(_lib.load().raae_event_elapsed_ms(self.h, stop.h, C.byref(ms)), "raae_event_elapsed_ms")
+        return ms.value

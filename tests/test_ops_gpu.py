@@ -1,0 +1,343 @@
+"""Per-kernel parity tests (GPU): each C-ABI entry point against a plain PyTorch fp32
+CPU reference of the same op (autograd for the backward).  Tolerances are written next
+to each assert; fp32 everywhere, differences come from summation order only.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from rankaae_amd import ops, _lib
+    DEV = torch.device("cuda:0")
+
+
+def dev(t, dtype=torch.float32):
+    return t.to(dtype).contiguous().to(DEV)
+
+
+def close(a, b, rtol, atol, what=""):
+    a = a.detach().cpu().double().numpy()
+    b = b.detach().cpu().double().numpy()
+    err = np.abs(a - b)
+    tol = atol + rtol * np.abs(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert np.all(err <= tol), f"{what}: max err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}, " \
+                               f"ref {b.flat[err.argmax()]:.6e} got {a.flat[err.argmax()]:.6e}"
+
+
+def _chain_ref(x, w0, b0, s0, mask0, w1, b1, out_kind):
+    z0 = F.linear(x, w0, b0)
+    a0 = F.prelu(z0, s0)
+    y0 = F.batch_norm(a0, None, None, training=True, eps=1e-5)
+    x1 = y0 * mask0 if mask0 is not None else y0
+    z1 = F.linear(x1, w1, b1)
+    if out_kind == "softplus":
+        return z0, F.softplus(z1, beta=2), y0
+    return z0, z1, y0
+
+
+@pytest.mark.parametrize("B,K,H,N,outk,drop", [
+    (256, 256, 64, 64, "raw", True), (36, 256, 64, 6, "raw", True), (100, 6, 64, 256, "softplus", True),
+    (64, 13, 64, 512, "softplus", False), (77, 512, 64, 13, "raw", True), (4096, 64, 64, 64, "raw", True),
+    (5000, 256, 64, 6, "raw", True),
+])
+def test_dense_chain_fwd_bwd(B, K, H, N, outk, drop):
+    g = torch.Generator().manual_seed(B * 7 + K)
+    x = torch.randn(B, K, generator=g)
+    w0 = torch.randn(H, K, generator=g) / K ** 0.5
+    b0 = torch.randn(H, generator=g) * 0.1
+    s0 = torch.rand(H, generator=g) * 0.5 - 0.1          # PReLU slopes, some negative
+    w1 = torch.randn(N, H, generator=g) / H ** 0.5
+    b1 = torch.randn(N, generator=g) * 0.1
+    mask0 = (torch.rand(B, H, generator=g) < 0.9).float() / 0.9 if drop else None
+    gout = torch.randn(B, N, generator=g)
+
+    # ---- reference (CPU autograd) ----
+    xr = x.clone().requires_grad_(True)
+    pr = [t.clone().requires_grad_(True) for t in (w0, b0, s0, w1, b1)]
+    z0r, outr, y0r = _chain_ref(xr, pr[0], pr[1], pr[2], mask0, pr[3], pr[4], outk)
+    (outr * gout).sum().backward()
+
+    # ---- HIP ----
+    xd, w0d, b0d, s0d, w1d, b1d = map(dev, (x, w0, b0, s0, w1, b1))
+    md = dev(mask0) if drop else None
+    z0 = torch.empty(B, H, device=DEV)
+    out = torch.empty(B, N, device=DEV)
+    part0 = torch.zeros(_lib.RAAE_MAX_PARTS, H, 2, dtype=torch.float64, device=DEV)
+    np0 = ops.dense_fwd(xd, B, K, _lib.IN_NONE, None, None, None, w0d, b0d, H, z0, _lib.OUT_STATS_PRELU, s0d, part0)
+    rm = torch.zeros(H, device=DEV)
+    rv = torch.ones(H, device=DEV)
+    bn0 = ops.make_bn(part0, np0, B, rm, rv, update_running=True)
+    ok = _lib.OUT_SOFTPLUS if outk == "softplus" else _lib.OUT_RAW
+    ops.dense_fwd(z0, B, H, _lib.IN_PRELU_BN_DROP, s0d, bn0, md, w1d, b1d, N, out, ok)
+    torch.cuda.synchronize()
+    close(z0, z0r, 2e-5, 2e-5, "z0")
+    close(out, outr, 1e-4, 1e-4, "out")
+    # running stats as torch.nn.BatchNorm1d would update them (momentum 0.1, unbiased var)
+    a0 = F.prelu(z0r.detach(), s0)
+    close(rm, 0.1 * a0.mean(0), 1e-4, 1e-6, "running_mean")
+    close(rv, 0.9 + 0.1 * a0.var(0, unbiased=True), 1e-4, 1e-6, "running_var")
+
+    # backward: layer 1 then layer 0
+    bn0.update_running = 0
+    n_all = H * K + H + H + N * H + N          # slab layout: w0 | b0 | s0 | w1 | b1
+    off_w0, off_b0, off_s0, off_w1, off_b1 = 0, H * K, H * K + H, H * K + 2 * H, H * K + 2 * H + N * H
+    stride = (n_all + 63) // 64 * 64
+    slabs = torch.zeros(256, stride, device=DEV)
+    gd = dev(gout)
+    dx1 = torch.empty(B, H, device=DEV)
+    dxp1 = torch.zeros(_lib.RAAE_MAX_PARTS, H, 2, dtype=torch.float64, device=DEV)
+    gk = _lib.G_SOFTPLUS if outk == "softplus" else _lib.G_DIRECT
+    ns1 = ops.dense_bwd(gd, gk, None, 0, out, None, None, B, N, z0, H, _lib.IN_PRELU_BN_DROP, s0d, bn0, md, w1d,
+                        slabs[0, off_w1:], slabs[0, off_b1:], None, stride, dx1, dxp1)
+    dx0 = torch.empty(B, K, device=DEV)
+    ns0 = ops.dense_bwd(dx1, _lib.G_PRELU_BN, dxp1, ns1, z0, s0d, bn0, B, H, xd, K, _lib.IN_NONE, None, None, None, w0d,
+                        slabs[0, off_w0:], slabs[0, off_b0:], slabs[0, off_s0:], stride, dx0, None)
+    torch.cuda.synchronize()
+    scale = float(gout.abs().mean()) * B ** 0.5
+    dw1 = slabs[:ns1, off_w1:off_w1 + N * H].sum(0).view(N, H)
+    db1 = slabs[:ns1, off_b1:off_b1 + N].sum(0)
+    dw0 = slabs[:ns0, off_w0:off_w0 + H * K].sum(0).view(H, K)
+    db0 = slabs[:ns0, off_b0:off_b0 + H].sum(0)
+    ds0 = slabs[:ns0, off_s0:off_s0 + H].sum(0)
+    close(dw1, pr[3].grad, 2e-4, 2e-5 * scale, "dw1")
+    close(db1, pr[4].grad, 2e-4, 2e-5 * scale, "db1")
+    close(dw0, pr[0].grad, 5e-4, 5e-5 * scale, "dw0")
+    close(db0, pr[1].grad, 5e-4, 5e-5 * scale, "db0")
+    close(ds0, pr[2].grad, 5e-4, 5e-5 * scale, "dslope0")
+    close(dx0, xr.grad, 5e-4, 5e-5, "dx0")
+
+
+def test_dense_prelu_drop_no_bn():
+    """Discriminator-style layers: PReLU -> Dropout -> Linear, no BatchNorm."""
+    g = torch.Generator().manual_seed(5)
+    B, K, H = 300, 6, 64
+    x = torch.randn(B, K, generator=g)
+    w0, b0, s0 = torch.randn(H, K, generator=g) * 0.4, torch.randn(H, generator=g) * 0.1, torch.rand(H, generator=g) * 0.3
+    w1, b1 = torch.randn(1, H, generator=g) * 0.2, torch.randn(1, generator=g)
+    mask = (torch.rand(B, H, generator=g) < 0.94).float() / 0.94
+    gout = torch.randn(B, 1, generator=g)
+    xr = x.clone().requires_grad_(True)
+    pr = [t.clone().requires_grad_(True) for t in (w0, b0, s0, w1, b1)]
+    z0r = F.linear(xr, pr[0], pr[1])
+    outr = F.linear(F.prelu(z0r, pr[2]) * mask, pr[3], pr[4])
+    (outr * gout).sum().backward()
+    xd, w0d, b0d, s0d, w1d, b1d, md, gd = map(dev, (x, w0, b0, s0, w1, b1, mask, gout))
+    z0 = torch.empty(B, H, device=DEV)
+    out = torch.empty(B, 1, device=DEV)
+    ops.dense_fwd(xd, B, K, _lib.IN_NONE, None, None, None, w0d, b0d, H, z0, _lib.OUT_RAW)
+    ops.dense_fwd(z0, B, H, _lib.IN_PRELU_DROP, s0d, None, md, w1d, b1d, 1, out, _lib.OUT_RAW)
+    close(out, outr, 1e-5, 1e-5, "logit")
+    stride = 1024
+    slabs = torch.zeros(256, stride, device=DEV)
+    dx1 = torch.empty(B, H, device=DEV)
+    ns1 = ops.dense_bwd(gd, _lib.G_DIRECT, None, 0, None, None, None, B, 1, z0, H, _lib.IN_PRELU_DROP, s0d, None, md,
+                        w1d, slabs[0, 0:], slabs[0, 64:], None, stride, dx1, None)
+    dx0 = torch.empty(B, K, device=DEV)
+    ns0 = ops.dense_bwd(dx1, _lib.G_PRELU, None, 0, z0, s0d, None, B, H, xd, K, _lib.IN_NONE, None, None, None, w0d,
+                        slabs[0, 128:], slabs[0, 512:], slabs[0, 576:], stride, dx0, None)
+    close(slabs[:ns1, 0:H].sum(0).view(1, H), pr[3].grad, 1e-4, 1e-4, "dw1")
+    close(slabs[:ns1, 64:65].sum(0), pr[4].grad, 1e-4, 1e-4, "db1")
+    close(slabs[:ns0, 128:128 + H * K].sum(0).view(H, K), pr[0].grad, 1e-4, 1e-4, "dw0")
+    close(slabs[:ns0, 512:512 + H].sum(0), pr[1].grad, 1e-4, 1e-4, "db0")
+    close(slabs[:ns0, 576:576 + H].sum(0), pr[2].grad, 1e-4, 1e-4, "ds0")
+    close(dx0, xr.grad, 1e-4, 1e-5, "dx0")
+
+
+@pytest.mark.parametrize("B,C", [(256, 6), (36, 13), (4096, 6), (1050, 64)])
+def test_style_bn(B, C):
+    g = torch.Generator().manual_seed(B + C)
+    z = torch.randn(B, C, generator=g) * 2 + 0.5
+    gout = torch.randn(B, C, generator=g)
+    zr = z.clone().requires_grad_(True)
+    yr = F.batch_norm(zr, None, None, training=True, eps=1e-5)
+    (yr * gout).sum().backward()
+    # partials as a producer would emit them (two "workgroups")
+    part = torch.zeros(4, C, 2, dtype=torch.float64)
+    h = B // 2
+    for i, sl in enumerate((z[:h], z[h:])):
+        part[i, :, 0] = sl.double().sum(0)
+        part[i, :, 1] = (sl.double() ** 2).sum(0)
+    pd = part.to(DEV)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    bn = ops.make_bn(pd, 2, B, rm, rv, update_running=True)
+    y = torch.empty(B, C, device=DEV)
+    ops.style_bn_fwd(dev(z), B, C, bn, y)
+    close(y, yr, 1e-5, 1e-5, "styles")
+    close(rm, 0.1 * z.mean(0), 1e-5, 1e-6, "rm")
+    bn.update_running = 0
+    dz = torch.empty(B, C, device=DEV)
+    ops.style_bn_bwd(dev(gout), y, B, C, bn, dz)
+    close(dz, zr.grad, 1e-4, 2e-5, "dz")
+    # eval mode
+    bn_e = ops.make_bn(None, 0, 0, rm, rv)
+    ops.style_bn_fwd(dev(z), B, C, bn_e, y)
+    close(y, (z - rm.cpu()) / torch.sqrt(rv.cpu() + 1e-5), 1e-5, 1e-6, "eval")
+
+
+@pytest.mark.parametrize("B,K,ld,act", [(256, 5, 6, True), (36, 5, 6, True), (1050, 5, 6, True), (300, 12, 13, True),
+                                        (257, 1, 1, False), (4096, 5, 6, True)])
+def test_rank_loss(B, K, ld, act):
+    from oracle.ref_train import kendall_constraint, kendall_closed_form
+    g = torch.Generator().manual_seed(B + K)
+    d = torch.randn(B, K, generator=g)
+    d[:, min(1, K - 1)] = torch.randint(4, 7, (B,), generator=g).float()     # ties
+    z = torch.randn(B, ld, generator=g)
+    if B <= 1100:
+        zr = z.clone().requires_grad_(True)
+        lr = kendall_constraint(d, zr[:, :K], activate=act)
+        lr.backward()
+        gref, lref = zr.grad, float(lr)
+    else:   # literal form needs B^2*K floats; use the float64 closed form (pinned to it on CPU)
+        l64, g64 = kendall_closed_form(d, z[:, :K], activate=act)
+        gref = torch.zeros(B, ld, dtype=torch.float64)
+        gref[:, :K] = g64
+        lref = float(l64)
+    work = torch.empty(ops.rank_loss_work_bytes(B, K), dtype=torch.uint8, device=DEV)
+    loss = torch.zeros(1, device=DEV)
+    dz = torch.full((B, ld), 7.0, device=DEV)
+    ops.rank_loss_fwd_bwd(dev(d), K, dev(z), ld, B, K, act, work, loss, dz)
+    assert abs(float(loss) - lref) <= 1e-5 * abs(lref) + 1e-7, (float(loss), lref)
+    close(dz, gref, 1e-5, 1e-9, "dz")
+    ops.rank_loss_fwd_bwd(dev(d), K, dev(z), ld, B, K, act, work, loss, None)   # validation form
+    assert abs(float(loss) - lref) <= 1e-5 * abs(lref) + 1e-7
+
+
+@pytest.mark.parametrize("B,L,scale", [(256, 256, True), (36, 256, True), (1050, 256, False), (64, 512, True)])
+def test_recon_loss(B, L, scale):
+    from oracle.ref_train import recon_loss
+    g = torch.Generator().manual_seed(B)
+    x = torch.rand(B, L, generator=g) + 0.2
+    y = (x + 0.3 * torch.randn(B, L, generator=g)).requires_grad_(True)
+    with torch.no_grad():
+        y[0] *= 2.0      # clamp branch (ratio > 1.3)
+        y[1] *= 0.3      # ratio < 0.7
+    lr = recon_loss(x, y, scale=scale)
+    lr.backward()
+    part = torch.zeros(_lib.RAAE_MAX_PARTS, dtype=torch.float64, device=DEV)
+    dy = torch.empty(B, L, device=DEV)
+    n = ops.recon_loss_fwd_bwd(dev(x), dev(y.detach()), B, L, scale, part, dy)
+    out = torch.zeros(8, device=DEV)
+    ops.loss_finalize(part, n, 1.0, out, 2)
+    assert abs(float(out[2]) - float(lr)) <= 1e-5 * abs(float(lr)), (float(out[2]), float(lr))
+    close(dy, y.grad, 1e-4, 1e-9, "dy")
+
+
+@pytest.mark.parametrize("B,L", [(256, 256), (36, 256), (64, 512), (5, 20)])
+def test_smooth_loss(B, L):
+    from oracle.ref_train import smoothness_loss
+    from oracle.ref_model import gaussian_taps
+    g = torch.Generator().manual_seed(L)
+    x = (torch.rand(B, L, generator=g) + 0.1 * torch.randn(B, L, generator=g)).requires_grad_(True)
+    lr = smoothness_loss(x, 17)
+    lr.backward()
+    part = torch.zeros(_lib.RAAE_MAX_PARTS, dtype=torch.float64, device=DEV)
+    dx = torch.empty(B, L, device=DEV)
+    n = ops.smooth_loss_fwd_bwd(dev(x.detach()), B, L, gaussian_taps(17, 3.0).tolist(), part, dx)
+    out = torch.zeros(8, device=DEV)
+    ops.loss_finalize(part, n, 1.0, out, 4)
+    assert abs(float(out[4]) - float(lr)) <= 2e-5 * abs(float(lr)), (float(out[4]), float(lr))
+    close(dx, x.grad, 1e-4, 1e-9, "dx")
+
+
+def test_mse_and_bce():
+    g = torch.Generator().manual_seed(1)
+    a = torch.randn(300, 6, generator=g).requires_grad_(True)
+    b = torch.randn(300, 6, generator=g)
+    lr = F.mse_loss(a, b)
+    lr.backward()
+    part = torch.zeros(_lib.RAAE_MAX_PARTS, dtype=torch.float64, device=DEV)
+    da = torch.empty(300, 6, device=DEV)
+    n = ops.mse_fwd_bwd(dev(a.detach()), dev(b), 1800, part, da)
+    out = torch.zeros(8, device=DEV)
+    ops.loss_finalize(part, n, 1.0, out, 3, 5)
+    ops.loss_finalize(part, n, 1.0, out, 3, 5)
+    assert abs(float(out[3]) - float(lr)) < 1e-6 * float(lr)
+    assert abs(float(out[5]) - 2 * float(lr)) < 1e-6 * float(lr)      # accumulating slot
+    close(da, a.grad, 1e-5, 1e-9, "da")
+
+    o = (torch.randn(256 + 36, generator=g) * 3).requires_grad_(True)
+    bce = torch.nn.BCEWithLogitsLoss()
+    lr = bce(o[:256], torch.ones(256)) + bce(o[256:], torch.zeros(36))
+    lr.backward()
+    loss = torch.zeros(1, device=DEV)
+    do = torch.empty(292, device=DEV)
+    ops.bce_pair_fwd_bwd(dev(o.detach()), 256, 36, loss, do)
+    assert abs(float(loss) - float(lr)) < 1e-6 * float(lr)
+    close(do, o.grad, 1e-5, 1e-9, "dlogits")
+
+
+@pytest.mark.parametrize("decoupled,wd", [(True, 0.01), (False, 0.0), (False, 0.01)])
+def test_adam_matches_torch(decoupled, wd):
+    g = torch.Generator().manual_seed(11)
+    n = 64 * 40
+    p0 = torch.randn(n, generator=g)
+    ref = p0.clone().requires_grad_(True)
+    cls = torch.optim.AdamW if decoupled else torch.optim.Adam
+    opt = cls([ref], lr=0.01, betas=(0.99, 0.9999), weight_decay=wd)
+    p, m, v = dev(p0), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    hyper = torch.tensor([0.01, 0.99, 0.9999, 1e-8, wd], dtype=torch.float64, device=DEV)
+    step = torch.zeros(4, dtype=torch.int32, device=DEV)
+    rngc = torch.zeros(1, dtype=torch.int64, device=DEV)
+    cursor = torch.zeros(1, dtype=torch.int32, device=DEV)
+    nslab = 3
+    seg = torch.full((n // 64,), nslab, dtype=torch.uint8, device=DEV)
+    seg[5] = 0          # one segment "without gradient": must be left untouched
+    for it in range(5):
+        slabs = torch.randn(nslab, n, generator=g) * (0.0 if it == 3 else 1.0)     # one all-zero gradient step
+        grad = (slabs[0] + slabs[1]) + slabs[2]
+        ref.grad = grad.clone()
+        opt.step()
+        ops.step_tick(step, 4, 0b0101, rngc, cursor, 256)
+        ops.adam_step(p, m, v, dev(slabs), n, seg, n, hyper, step[2:], decoupled)
+    torch.cuda.synchronize()
+    assert step.tolist() == [5, 0, 5, 0] and int(rngc) == 5 and int(cursor) == 5 * 256
+    pr = ref.detach().clone()
+    pr[5 * 64:6 * 64] = p0[5 * 64:6 * 64]
+    close(p, pr, 2e-6, 2e-7, "params after 5 steps")
+
+
+def test_rng_fill_statistics():
+    n_norm, n_mask = 1 << 20, 1 << 20
+    desc = torch.tensor([[0, n_norm, 0, 0], [n_norm, n_mask, 1, 0]], dtype=torch.int32, device=DEV)
+    scale = torch.tensor([1.0, 0.96], device=DEV)
+    tape = torch.zeros(n_norm + n_mask, device=DEV)
+    ctr = torch.zeros(1, dtype=torch.int64, device=DEV)
+    ops.rng_fill(tape, desc, scale, 2, n_norm + n_mask, 1234, ctr)
+    a = tape[:n_norm].cpu().double()
+    assert abs(float(a.mean())) < 5e-3 and abs(float(a.std()) - 1) < 5e-3
+    assert abs(float((a ** 4).mean()) - 3.0) < 0.1
+    mk = tape[n_norm:].cpu()
+    vals = torch.unique(mk)
+    assert len(vals) == 2 and float(vals[0]) == 0.0 and abs(float(vals[1]) - 1 / 0.96) < 1e-6
+    assert abs(float((mk > 0).float().mean()) - 0.96) < 2e-3
+    t2 = torch.zeros_like(tape)
+    ops.rng_fill(t2, desc, scale, 2, n_norm + n_mask, 1234, ctr)
+    assert torch.equal(tape, t2)                       # same (seed, counter) -> same tape
+    ctr += 1
+    ops.rng_fill(t2, desc, scale, 2, n_norm + n_mask, 1234, ctr)
+    assert not torch.equal(tape, t2)
+
+
+def test_gather_batch_and_disc_input():
+    g = torch.Generator().manual_seed(2)
+    spec, aux = torch.randn(100, 32, generator=g), torch.randn(100, 5, generator=g)
+    idx = torch.randperm(100, generator=g)
+    noise = torch.randn(16, 32, generator=g)
+    cursor = torch.tensor([48], dtype=torch.int32, device=DEV)
+    so, ao = torch.empty(16, 32, device=DEV), torch.empty(16, 5, device=DEV)
+    ops.gather_batch(dev(spec), dev(aux), idx.to(DEV), cursor, dev(noise), 0.02, 16, 32, 5, so, ao)
+    rows = idx[32:48]
+    close(so, spec[rows] + noise * 0.02, 1e-6, 1e-7, "spec")
+    close(ao, aux[rows], 0, 0, "aux")
+    zr, st, nz = torch.randn(8, 6, generator=g), torch.randn(5, 6, generator=g), torch.randn(13, 6, generator=g)
+    out = torch.empty(13, 6, device=DEV)
+    ops.disc_input(dev(zr), dev(st), dev(nz), 0.56, 8, 5, 6, out)
+    close(out, torch.cat([zr, st]) + 0.56 * nz, 1e-6, 1e-7, "disc_input")
+    al = torch.tensor([0.25], device=DEV)
+    dst = torch.empty(5, 6, device=DEV)
+    ops.scale_by_dev(out[8:], al, -1.0, 30, dst)
+    close(dst, -0.25 * out[8:].cpu(), 1e-6, 0, "grl")
