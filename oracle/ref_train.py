@@ -161,6 +161,7 @@ class OracleTrainer:
         self.anomaly = anomaly
         self.last = {}
         self.phase_hook = None   # callable(phase_name) invoked after backward, before optimizer.step
+        self.post_hook = None    # callable(phase_name) invoked right after optimizer.step
 
     # trainer.py:333-408
     def _load_optimizers(self):
@@ -194,6 +195,8 @@ class OracleTrainer:
         if self.phase_hook is not None:
             self.phase_hook(name)
         self.optimizers[name].step()
+        if self.post_hook is not None:
+            self.post_hook(name)
 
     # trainer.py:103-204 -- one batch through the five phases
     def train_step(self, spec_in, aux_in, alpha_, epoch=0):

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
     const int gcol0 = wideN ? tid : (tid & 63);
     const int grow0 = wideN ? 0 : (tid >> 6);
     const int grstep = wideN ? 1 : 4;
-    float db_acc[2] = {0.f, 0.f}, ds_acc[2] = {0.f, 0.f};
+    double db_acc[2] = {0.0, 0.0}, ds_acc[2] = {0.0, 0.0};
 
     const int ntiles = (a.B + 15) >> 4;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -193,9 +193,9 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
                             da = o_rstd[n] * (gv - m1[n] - y * m2[n]);
                         }
                         if (zv > 0.f) dz = da;
-                        else { dz = da * o_slope[n]; ds_acc[h] += da * zv; }
+                        else { dz = da * o_slope[n]; ds_acc[h] += (double)da * (double)zv; }
                     }
-                    db_acc[h] += dz;
+                    db_acc[h] += (double)dz;
                 }
                 Gs[r * a.pitch_g + n] = dz;
             }
@@ -288,13 +288,13 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
         for (int h = 0; h < 2; ++h) {
             const int n = tid + h * 256;
             if (n < a.N) {
-                a.db[slab + n] = db_acc[h];
-                if (a.dslope != nullptr) a.dslope[slab + n] = ds_acc[h];
+                a.db[slab + n] = (float)db_acc[h];
+                if (a.dslope != nullptr) a.dslope[slab + n] = (float)ds_acc[h];
             }
         }
     } else {
-        red[tid] = db_acc[0];
-        red[256 + tid] = ds_acc[0];
+        red[tid] = (float)db_acc[0];
+        red[256 + tid] = (float)ds_acc[0];
         __syncthreads();
         if (tid < a.N) {
             a.db[slab + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);

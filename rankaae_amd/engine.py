@@ -1,0 +1,681 @@
+"""The MI355X step engine: the five-phase adversarial-autoencoder training step of the
+reference (``sc/clustering/trainer.py:103-204``) as an explicit forward/backward program
+of fused HIP kernels over a flat parameter arena, captured once per batch shape into a
+hipGraph and replayed.
+
+Design (DESIGN.md has the long form):
+  * parameters live in ONE fp32 arena ordered [discriminator | encoder | decoder] so every
+    optimizer of the reference (trainer.py:333-397) covers one contiguous range; the
+    ``nn.Module`` containers hold views into it;
+  * parameter gradients leave each backward kernel as per-workgroup *slabs* that the fused
+    Adam kernel sums in fixed order -- no atomics, no zeroing, bitwise reproducible;
+  * every random number of a step (spectral noise, dropout scales, latent samples) is a
+    slot of one *tape* buffer: ``rng_mode="philox"`` fills it on the device inside the
+    graph; ``rng_mode="host"`` draws it from the global torch CPU generator in the
+    reference's consumption order (parity mode) and uploads it;
+  * per-step scalars that change between replays (Adam step counts, learning rates, the
+    gradient-reversal alpha, the epoch row cursor) live in device memory.
+PyTorch is used for device memory and the current stream only.
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib, ops
+from ._lib import (IN_NONE, IN_PRELU_BN_DROP, IN_PRELU_DROP, OUT_RAW, OUT_STATS_PRELU, OUT_STATS_RAW, OUT_SOFTPLUS,
+                   OUT_RELU, G_DIRECT, G_SOFTPLUS, G_PRELU_BN, G_PRELU, G_RELU, RAAE_MAX_PARTS)
+
+OPT_NAMES = ["adversarial", "correlation", "reconstruction", "mutual_info", "smoothness"]
+LOSS_SLOTS = {"adversarial": 0, "kendall": 1, "recon": 2, "mutual_info": 3, "smooth": 4, "mi_accum": 5}
+
+
+def gaussian_taps(kernel_size=17, sigma=3.0):
+    """Normalised Gaussian taps in float32 (what ``GaussianSmoothing`` builds, reference
+    ``model.py:187-200``): computed here with numpy float32 arithmetic."""
+    t = np.arange(kernel_size, dtype=np.float32)
+    mean = np.float32((kernel_size - 1) / 2)
+    k = np.float32(1 / (sigma * math.sqrt(2 * math.pi))) * np.exp(
+        -(((t - mean) / np.float32(sigma)) ** 2) / np.float32(2)).astype(np.float32)
+    return (k / k.sum(dtype=np.float32)).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------ arena
+class Arena:
+    """Flat fp32 parameter arena; tensors start at multiples of 64 floats."""
+
+    def __init__(self, named_modules, device):
+        self.device = device
+        self.ranges, self.offsets, plan, off = {}, {}, [], 0
+        for name, mod in named_modules:
+            lo = off
+            for p in mod.parameters():
+                plan.append((p, off))
+                self.offsets[id(p)] = off
+                off += (p.numel() + 63) // 64 * 64
+            self.ranges[name] = (lo, off)
+        self.n = off
+        self.P = torch.zeros(self.n, dtype=torch.float32, device=device)
+        for p, o in plan:
+            view = self.P[o:o + p.numel()].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+        for _, mod in named_modules:      # buffers (BN running stats) just move to the device
+            for b in mod.buffers():
+                b.data = b.data.to(device)
+
+    def off(self, p):
+        return self.offsets[id(p)]
+
+
+class OptState:
+    """One optimizer of ``Trainer.load_optimizers``: a contiguous arena range + moments."""
+
+    def __init__(self, index, name, lo, hi, lr, betas, eps, wd, device):
+        self.index, self.name, self.lo, self.hi = index, name, lo, hi
+        self.lr, self.betas, self.eps, self.wd = float(lr), betas, float(eps), float(wd)
+        self.m = torch.zeros(hi - lo, device=device)
+        self.v = torch.zeros(hi - lo, device=device)
+        self.hyper = torch.zeros(5, dtype=torch.float64, device=device)
+        self.push()
+
+    def push(self):
+        self.hyper.copy_(torch.tensor([self.lr, self.betas[0], self.betas[1], self.eps, self.wd],
+                                      dtype=torch.float64))
+
+
+# ------------------------------------------------------------------------------ tape
+class Tape:
+    """Per-step random tape: named slots (4-float aligned) + the reference's draw order."""
+
+    def __init__(self):
+        self.total = 0
+        self.segs = []      # (offset, count, kind, keep)   kind 0 = N(0,1), 1 = dropout scale
+        self.draws = []     # in reference order: ("normal"|"mask", offset, shape, keep) | ("int64",)
+        self.buf = None
+
+    def slot(self, count, kind, keep=1.0):
+        off = self.total
+        self.segs.append((off, count, kind, keep))
+        self.total += (count + 3) // 4 * 4
+        return off
+
+    def draw(self, kind, off, shape, keep=1.0):
+        self.draws.append((kind, off, tuple(shape), keep))
+
+    def finalize(self, device):
+        self.buf = torch.zeros(max(self.total, 4), device=device)
+        d = torch.tensor([[o, c, k, 0] for o, c, k, _ in self.segs], dtype=torch.int32)
+        self.seg_desc = d.to(device)
+        self.seg_scale = torch.tensor([kp for *_, kp in self.segs], dtype=torch.float32).to(device)
+        self.host = torch.zeros(max(self.total, 4)).pin_memory() if torch.cuda.is_available() else None
+
+    def view(self, off, *shape):
+        n = int(np.prod(shape))
+        return self.buf[off:off + n].view(*shape)
+
+    def fill_host(self):
+        """Parity mode: draw from the GLOBAL torch CPU generator exactly as the reference's
+        ``randn_like`` / ``nn.Dropout`` / ``randn`` calls would (finding 9)."""
+        for kind, off, shape, keep in self.draws:
+            n = int(np.prod(shape))
+            if kind == "normal":
+                self.host[off:off + n] = torch.randn(*shape).reshape(-1)
+            elif kind == "mask":
+                self.host[off:off + n] = torch.empty(*shape).bernoulli_(keep).div_(keep).reshape(-1)
+            else:
+                raise ValueError(kind)
+        self.buf.copy_(self.host, non_blocking=True)
+
+
+# ------------------------------------------------------------------------------ dense nets
+class DenseLayer:
+    def __init__(self, lin):
+        self.lin, self.w, self.b = lin, lin.weight, lin.bias
+        self.N, self.K = lin.out_features, lin.in_features
+        self.prelu = None      # nn.PReLU following this layer
+        self.bn = None         # nn.BatchNorm1d following the PReLU (or the Linear, for the style layer)
+        self.p = 0.0           # dropout after it
+
+
+def dense_layers(seq):
+    layers = []
+    for m in seq:
+        if isinstance(m, nn.Linear):
+            layers.append(DenseLayer(m))
+        elif isinstance(m, nn.PReLU):
+            layers[-1].prelu = m
+        elif isinstance(m, nn.BatchNorm1d):
+            layers[-1].bn = m
+        elif isinstance(m, nn.Dropout):
+            layers[-1].p = m.p
+    return layers
+
+
+class FCNet:
+    """Emitter for ``FCEncoder`` / ``FCDecoder``: one fused dense kernel per layer."""
+
+    def __init__(self, module, kind, eng):
+        self.module, self.kind, self.eng = module, kind, eng
+        self.layers = dense_layers(module.main)
+        self.in_dim, self.out_dim = self.layers[0].K, self.layers[-1].N
+        self.final_relu = kind == "dec" and isinstance(module.main[-1], nn.ReLU)
+        self.bn_modules = [l.bn for l in self.layers if l.bn is not None]
+
+    def alloc(self, b):
+        dev = self.eng.device
+        ws = type("WS", (), {})()
+        ws.b = b
+        ws.z = [torch.empty(b, l.N, device=dev) for l in self.layers]
+        ws.part = [torch.zeros(RAAE_MAX_PARTS, l.N, 2, dtype=torch.float64, device=dev) for l in self.layers]
+        ws.nparts = [0] * len(self.layers)
+        wmax = max(max(l.N, l.K) for l in self.layers)
+        ws.dx = [torch.empty(b, wmax, device=dev) for _ in range(2)]
+        ws.dxp = [torch.zeros(RAAE_MAX_PARTS, wmax, 2, dtype=torch.float64, device=dev) for _ in range(2)]
+        if self.kind == "enc":
+            ws.styles = torch.empty(b, self.out_dim, device=dev)
+            ws.dz_last = torch.empty(b, self.out_dim, device=dev)
+            ws.out = ws.styles
+        else:
+            ws.out = ws.z[-1]
+        return ws
+
+    def mask_slots(self, tape, b, train=True):
+        """Allocate + record (in forward order) the dropout masks of one forward pass."""
+        masks = []
+        for l in self.layers[:-1]:
+            if train and l.p > 0:
+                off = tape.slot(b * l.N, 1, 1.0 - l.p)
+                tape.draw("mask", off, (b, l.N), 1.0 - l.p)
+                masks.append((off, (b, l.N)))
+            else:
+                masks.append(None)
+        return masks
+
+    def _bn_in(self, ws, i, train, update):
+        p = self.layers[i]
+        if train:
+            return ops.make_bn(ws.part[i], ws.nparts[i], ws.b, p.bn.running_mean, p.bn.running_var,
+                               p.bn.momentum, p.bn.eps, update)
+        return ops.make_bn(None, 0, 0, p.bn.running_mean, p.bn.running_var, p.bn.momentum, p.bn.eps, False)
+
+    def forward(self, ws, x, masks, train=True):
+        eng, L, b = self.eng, self.layers, ws.b
+        for i, l in enumerate(L):
+            last = i == len(L) - 1
+            if i == 0:
+                xin, in_kind, slope, bn, mask = x, IN_NONE, None, None, None
+            else:
+                p = L[i - 1]
+                xin, in_kind, slope = ws.z[i - 1], IN_PRELU_BN_DROP, p.prelu.weight
+                bn = self._bn_in(ws, i - 1, train, True)
+                mask = eng.tape.view(masks[i - 1][0], *masks[i - 1][1]) if (train and masks[i - 1]) else None
+            if not last:
+                out_kind, oslope = OUT_STATS_PRELU, l.prelu.weight
+            elif self.kind == "enc":
+                out_kind, oslope = OUT_STATS_RAW, None
+            else:
+                out_kind, oslope = (OUT_RELU if self.final_relu else OUT_SOFTPLUS), None
+            ws.nparts[i] = ops.dense_fwd(xin, b, l.K, in_kind, slope, bn, mask, l.w, l.b, l.N, ws.z[i], out_kind,
+                                         oslope, ws.part[i])
+        if self.kind == "enc":
+            ops.style_bn_fwd(ws.z[-1], b, self.out_dim, self._bn_in(ws, len(L) - 1, train, True), ws.styles)
+        if train:
+            eng.count_bn(self.bn_modules)
+        return ws.out
+
+    def backward(self, ws, x, masks, g_out, dx_in=None):
+        """``g_out``: dL/d(output).  Writes parameter-gradient slabs; returns dL/d(input) in
+        ``dx_in`` (if given).  Records the slab count of every parameter it touched."""
+        eng, L, b = self.eng, self.layers, ws.b
+        n = len(L)
+        if self.kind == "enc":
+            ops.style_bn_bwd(g_out, ws.styles, b, self.out_dim, self._bn_in(ws, n - 1, True, False), ws.dz_last)
+            g, gk, gp, gnp = ws.dz_last, G_DIRECT, None, 0
+        else:
+            g, gk, gp, gnp = g_out, (G_RELU if self.final_relu else G_SOFTPLUS), None, 0
+        for i in reversed(range(n)):
+            l = L[i]
+            out_bn = self._bn_in(ws, i, True, False) if gk == G_PRELU_BN else None
+            oslope = l.prelu.weight if gk == G_PRELU_BN else None
+            if i == 0:
+                xin, in_kind, slope, bn, mask, dx, dxp = x, IN_NONE, None, None, None, dx_in, None
+            else:
+                p = L[i - 1]
+                xin, in_kind, slope = ws.z[i - 1], IN_PRELU_BN_DROP, p.prelu.weight
+                bn = self._bn_in(ws, i - 1, True, False)
+                mask = eng.tape.view(masks[i - 1][0], *masks[i - 1][1]) if masks[i - 1] else None
+                dx, dxp = ws.dx[i & 1], ws.dxp[i & 1]
+            ds = eng.gslab(l.prelu.weight) if gk == G_PRELU_BN else None
+            ns = ops.dense_bwd(g, gk, gp, gnp, ws.z[i], oslope, out_bn, b, l.N, xin, l.K, in_kind, slope, bn, mask,
+                               l.w, eng.gslab(l.w), eng.gslab(l.b), ds, eng.arena.n, dx, dxp)
+            eng.note_slabs([l.w, l.b] + ([l.prelu.weight] if ds is not None else []), ns)
+            g, gk, gp, gnp = dx, G_PRELU_BN, dxp, ns
+
+
+class DiscNet:
+    """Emitter for ``DiscriminatorFC`` on the concatenated [real; fake] batch."""
+
+    def __init__(self, module, eng):
+        self.module, self.eng = module, eng
+        self.layers = dense_layers(module.main)
+        self.nstyle = self.layers[0].K
+
+    def alloc(self, n_real, n_fake):
+        dev = self.eng.device
+        ws = type("WS", (), {})()
+        ws.n_real, ws.n_fake, ws.n = n_real, n_fake, n_real + n_fake
+        ws.x = torch.empty(ws.n, self.nstyle, device=dev)
+        ws.z = [torch.empty(ws.n, l.N, device=dev) for l in self.layers]
+        ws.dlogit = torch.empty(ws.n, 1, device=dev)
+        wmax = max(max(l.N, l.K) for l in self.layers)
+        ws.dx = [torch.empty(ws.n, wmax, device=dev) for _ in range(2)]
+        ws.dstyles = torch.empty(n_fake, self.nstyle, device=dev)
+        return ws
+
+    def tape_slots(self, tape, n_real, n_fake, train):
+        """Slots for z_real, input noise and dropout masks; draws recorded in the reference's
+        order: z_real; D(z_real): noise, masks; D(styles): noise, masks (functions.py:119-127)."""
+        n, ns = n_real + n_fake, self.nstyle
+        sl = type("S", (), {})()
+        sl.z_real = tape.slot(n_real * ns, 0)
+        tape.draw("normal", sl.z_real, (n_real, ns))
+        sl.noise, sl.masks = None, [None] * (len(self.layers) - 1)
+        if train:
+            sl.noise = tape.slot(n * ns, 0)
+            for i, l in enumerate(self.layers[:-1]):
+                if l.p > 0:
+                    sl.masks[i] = (tape.slot(n * l.N, 1, 1.0 - l.p), (n, l.N))
+            for rows, r0 in ((n_real, 0), (n_fake, n_real)):
+                tape.draw("normal", sl.noise + r0 * ns, (rows, ns))
+                for i, l in enumerate(self.layers[:-1]):
+                    if l.p > 0:
+                        tape.draw("mask", sl.masks[i][0] + r0 * l.N, (rows, l.N), 1.0 - l.p)
+        return sl
+
+    def forward_backward(self, ws, sl, styles, loss_out, train=True):
+        eng, L = self.eng, self.layers
+        tape = eng.tape
+        z_real = tape.view(sl.z_real, ws.n_real, self.nstyle)
+        noise = tape.view(sl.noise, ws.n, self.nstyle) if train else None
+        ops.disc_input(z_real, styles, noise, float(self.module.noise), ws.n_real, ws.n_fake, self.nstyle, ws.x)
+        masks = [tape.view(m[0], *m[1]) if (train and m) else None for m in sl.masks]
+        for i, l in enumerate(L):
+            if i == 0:
+                ops.dense_fwd(ws.x, ws.n, l.K, IN_NONE, None, None, None, l.w, l.b, l.N, ws.z[0], OUT_RAW)
+            else:
+                ops.dense_fwd(ws.z[i - 1], ws.n, l.K, IN_PRELU_DROP, L[i - 1].prelu.weight, None, masks[i - 1], l.w,
+                              l.b, l.N, ws.z[i], OUT_RAW)
+        ops.bce_pair_fwd_bwd(ws.z[-1], ws.n_real, ws.n_fake, loss_out, ws.dlogit if train else None)
+        if not train:
+            return None
+        g, gk = ws.dlogit, G_DIRECT
+        for i in reversed(range(len(L))):
+            l = L[i]
+            oslope = l.prelu.weight if gk == G_PRELU else None
+            ds = eng.gslab(l.prelu.weight) if gk == G_PRELU else None
+            dx = ws.dx[i & 1]
+            if i == 0:
+                ns = ops.dense_bwd(g, gk, None, 0, ws.z[0], oslope, None, ws.n, l.N, ws.x, l.K, IN_NONE, None, None,
+                                   None, l.w, eng.gslab(l.w), eng.gslab(l.b), ds, eng.arena.n, dx, None)
+            else:
+                ns = ops.dense_bwd(g, gk, None, 0, ws.z[i], oslope, None, ws.n, l.N, ws.z[i - 1], l.K, IN_PRELU_DROP,
+                                   L[i - 1].prelu.weight, None, masks[i - 1], l.w, eng.gslab(l.w), eng.gslab(l.b), ds,
+                                   eng.arena.n, dx, None)
+            eng.note_slabs([l.w, l.b] + ([l.prelu.weight] if ds is not None else []), ns)
+            g, gk = dx, G_PRELU
+        # gradient reversal: d styles = -alpha * dL/dx of the fake rows (model.py:15-22)
+        fake = g.view(-1)[ws.n_real * self.nstyle:(ws.n_real + ws.n_fake) * self.nstyle]
+        ops.scale_by_dev(fake, eng.alpha_dev, -1.0, ws.n_fake * self.nstyle, ws.dstyles)
+        return ws.dstyles
+
+
+# ------------------------------------------------------------------------------ the engine
+def _on_stream(fn):
+    """Run a StepEngine method on the engine's private HIP stream."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *a, **kw):
+        with torch.cuda.stream(self.stream):
+            return fn(self, *a, **kw)
+    return wrapper
+
+
+class StepPlan:
+    """Everything that depends on the batch size: workspaces, tape slots, captured graphs."""
+    pass
+
+
+class StepEngine:
+    def __init__(self, encoder, decoder, discriminator, cfg, device, rng_mode="philox", seed=0, use_graph=True):
+        if not torch.cuda.is_available():
+            raise RuntimeError("rankaae_amd.engine needs an MI355X (no CPU/PyTorch fallback for the training path)")
+        _lib.load()
+        self.cfg, self.device = dict(cfg), device
+        self.stream = torch.cuda.Stream(device=device)      # hipGraph capture is illegal on the null stream
+        self.stream.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(self.stream):
+            self._init(encoder, decoder, discriminator, cfg, device, rng_mode, seed, use_graph)
+
+    def _init(self, encoder, decoder, discriminator, cfg, device, rng_mode, seed, use_graph):
+        self.rng_mode, self.seed, self.use_graph = rng_mode, int(seed), use_graph
+        self.enc_mod, self.dec_mod, self.dis_mod = encoder, decoder, discriminator
+        self.arena = Arena([("disc", discriminator), ("enc", encoder), ("dec", decoder)], device)
+        self.max_slab = 256
+        self.G = torch.zeros(self.max_slab, self.arena.n, device=device)
+        from .nets_conv import CompactNet   # local import: conv emitters live in their own module
+        if cfg["ae_form"] == "FC":
+            self.enc, self.dec = FCNet(encoder, "enc", self), FCNet(decoder, "dec", self)
+        elif cfg["ae_form"] == "compact":
+            self.enc, self.dec = CompactNet(encoder, "enc", self), CompactNet(decoder, "dec", self)
+        else:
+            raise ValueError(f"ae_form {cfg['ae_form']!r} is not reachable in the reference (SURVEY.md finding 4)")
+        self.disc = DiscNet(discriminator, self)
+        self.nstyle, self.n_aux = cfg["nstyle"], cfg["n_aux"]
+        self.L = cfg["dim_in"]
+        self._make_optimizers()
+        self.steps_dev = torch.zeros(8, dtype=torch.int32, device=device)
+        self.cursor = torch.zeros(1, dtype=torch.int32, device=device)
+        self.rng_counter = torch.zeros(1, dtype=torch.int64, device=device)
+        self.alpha_dev = torch.zeros(1, device=device)
+        self.loss_out = torch.zeros(8, device=device)
+        self.taps = gaussian_taps(17, 3.0).tolist()
+        self.bn_counts = {}
+        self.plans = {}
+        self.tape = None
+        self._slab_notes = None
+        self.train_spec = self.train_aux = self.perm = None
+        self.phase_hook = None
+        self.post_phase_hook = None
+
+    # -- optimizers: trainer.py:333-397 (only the five that ever step under gradient reversal)
+    def _make_optimizers(self):
+        c, r = self.cfg, self.arena.ranges
+        lr = c["lr_base"]
+        self.decoupled = {"AdamW": True, "Adam": False}[c["optimizer_name"]]
+        default_wd = 0.01 if self.decoupled else 0.0
+        betas_d = (c["dis_beta"] * 0.9, c["dis_beta"] * 0.009 + 0.99)
+        spec = [("adversarial", r["disc"][0], r["enc"][1], c["lr_ratio_dis"] * lr, betas_d, default_wd),
+                ("correlation", r["enc"][0], r["enc"][1], c["lr_ratio_Corr"] * lr, (0.9, 0.999), c["weight_decay"]),
+                ("reconstruction", r["enc"][0], r["dec"][1], c["lr_ratio_Reconn"] * lr, (0.9, 0.999), c["weight_decay"]),
+                ("mutual_info", r["enc"][0], r["dec"][1], c["lr_ratio_Mutual"] * lr, (0.9, 0.999), default_wd),
+                ("smoothness", r["dec"][0], r["dec"][1], c["lr_ratio_Smooth"] * lr, (0.9, 0.999), c["weight_decay"])]
+        self.opts = {n: OptState(i, n, lo, hi, l, b, 1e-8, wd, self.device) for i, (n, lo, hi, l, b, wd) in enumerate(spec)}
+
+    # -- helpers used by the net emitters
+    def gslab(self, p):
+        return self.G[0, self.arena.off(p):]
+
+    def note_slabs(self, params, ns):
+        assert 1 <= ns <= self.max_slab
+        if self._slab_notes is not None:
+            for p in params:
+                o = self.arena.off(p)
+                self._slab_notes[o // 64:(o + p.numel() + 63) // 64] = ns
+
+    def count_bn(self, bns):
+        for bn in bns:
+            self.bn_counts[id(bn)] = self.bn_counts.get(id(bn), 0) + 1
+
+    @_on_stream
+    def set_data(self, train_spec, train_aux):
+        self.train_spec = torch.as_tensor(train_spec, dtype=torch.float32).contiguous().to(self.device)
+        self.train_aux = torch.as_tensor(train_aux, dtype=torch.float32).contiguous().to(self.device)
+        self.perm = torch.arange(len(self.train_spec), dtype=torch.int64, device=self.device)
+
+    @_on_stream
+    def set_epoch(self, perm, alpha):
+        self.perm.copy_(torch.as_tensor(perm, dtype=torch.int64))
+        self.cursor.zero_()
+        self.alpha_dev.fill_(float(alpha))
+        self.loss_out[LOSS_SLOTS["mi_accum"]] = 0.0
+
+    # -- plan construction
+    def plan(self, b):
+        if b in self.plans:
+            return self.plans[b]
+        P = StepPlan()
+        P.b = b
+        c, dev, ns = self.cfg, self.device, self.nstyle
+        bc = c["batch_size"]
+        tape = Tape()
+        P.tape = tape
+        P.spec = torch.empty(b, self.L, device=dev)
+        P.aux = torch.empty(b, self.n_aux, device=dev)
+        P.enc, P.dec = self.enc.alloc(b), self.dec.alloc(b)
+        P.disc = self.disc.alloc(bc, b)
+        train = True
+        # tape slots in the reference's consumption order
+        P.noise = tape.slot(b * self.L, 0)
+        tape.draw("normal", P.noise, (b, self.L))
+        P.m_enc, P.m_dec = [], []
+        P.m_enc.append(self.enc.mask_slots(tape, b))            # trainer.py:113
+        P.m_dec.append(self.dec.mask_slots(tape, b))            # :114
+        P.sl_disc = self.disc.tape_slots(tape, bc, b, train)    # phase A
+        P.m_enc.append(self.enc.mask_slots(tape, b))            # phase B :154
+        P.m_enc.append(self.enc.mask_slots(tape, b))            # phase C :165
+        P.m_dec.append(self.dec.mask_slots(tape, b))
+        P.m_enc.append(self.enc.mask_slots(tape, b))            # phase D :176
+        P.z_sample = tape.slot(b * ns, 0)
+        tape.draw("normal", P.z_sample, (b, ns))
+        P.m_dec.append(self.dec.mask_slots(tape, b))
+        P.m_enc.append(self.enc.mask_slots(tape, b))
+        P.n_draws_no_smooth = len(tape.draws)
+        P.m_enc.append(self.enc.mask_slots(tape, b))            # phase E :191
+        P.m_dec.append(self.dec.mask_slots(tape, b))
+        tape.finalize(dev)
+        P.rank_work = torch.empty(ops.rank_loss_work_bytes(b, self.n_aux), dtype=torch.uint8, device=dev)
+        P.dstyles = torch.empty(b, ns, device=dev)
+        P.dspec = torch.empty(b, self.L, device=dev)
+        P.dout = torch.empty(b, self.L, device=dev)
+        P.lpart = torch.zeros(RAAE_MAX_PARTS, dtype=torch.float64, device=dev)
+        P.seg = {n: torch.zeros(self.arena.n // 64, dtype=torch.uint8, device=dev) for n in OPT_NAMES}
+        P.graphs = {}
+        self.plans[b] = P
+        return P
+
+    # -- emit the step program (eagerly or under capture)
+    def _adam(self, P, name, notes_host):
+        o = self.opts[name]
+        if notes_host is not None:
+            P.seg[name].copy_(torch.from_numpy(notes_host))
+        if self.phase_hook is not None:      # debugging / parity tests: gradients before the update
+            self.phase_hook(name, P)
+        lo, n = o.lo, o.hi - o.lo
+        ops.adam_step(self.arena.P[lo:], o.m, o.v, self.G[0, lo:], self.arena.n, P.seg[name][lo // 64:], n, o.hyper,
+                      self.steps_dev[o.index:], self.decoupled)
+        if self.post_phase_hook is not None:  # parity tests: teacher forcing at phase granularity
+            self.post_phase_hook(name, P)
+
+    def _begin_phase(self, record):
+        self._slab_notes = np.zeros(self.arena.n // 64, dtype=np.uint8) if record else None
+
+    def emit_step(self, P, smooth, record):
+        """``record``: first (eager) emission -- slab counts are recorded into the Adam segment
+        tables.  Under graph capture ``record`` is False (no host->device copies)."""
+        c, b, ns = self.cfg, P.b, self.nstyle
+        self.tape = P.tape
+        tape = P.tape
+        mask_bits = 0b01111 | (0b10000 if smooth else 0)
+        ops.step_tick(self.steps_dev, 5, mask_bits, self.rng_counter, self.cursor, b)
+        if self.rng_mode == "philox":
+            ops.rng_fill(tape.buf, tape.seg_desc, tape.seg_scale, len(tape.segs), tape.total, self.seed,
+                         self.rng_counter)
+        ops.gather_batch(self.train_spec, self.train_aux, self.perm, self.cursor, tape.view(P.noise, b, self.L),
+                         float(c["spec_noise"]), b, self.L, self.n_aux, P.spec, P.aux)
+        enc, dec, E, D = self.enc, self.dec, P.enc, P.dec
+        lo = self.loss_out
+        # trainer.py:113-114
+        styles = enc.forward(E, P.spec, P.m_enc[0])
+        dec.forward(D, styles, P.m_dec[0])
+        # ---- phase A: adversarial (trainer.py:117-127)
+        self._begin_phase(record)
+        dst = self.disc.forward_backward(P.disc, P.sl_disc, styles, lo[0:1])
+        enc.backward(E, P.spec, P.m_enc[0], dst)
+        self._adam(P, "adversarial", self._slab_notes)
+        # ---- phase B: rank correlation (:153-161)
+        self._begin_phase(record)
+        styles = enc.forward(E, P.spec, P.m_enc[1])
+        ops.rank_loss_fwd_bwd(P.aux, self.n_aux, styles, ns, b, self.n_aux, c["kendall_activation"], P.rank_work,
+                              lo[1:2], P.dstyles)
+        enc.backward(E, P.spec, P.m_enc[1], P.dstyles)
+        self._adam(P, "correlation", self._slab_notes)
+        # ---- phase C: reconstruction (:164-172)
+        self._begin_phase(record)
+        styles = enc.forward(E, P.spec, P.m_enc[2])
+        out = dec.forward(D, styles, P.m_dec[1])
+        n = ops.recon_loss_fwd_bwd(P.spec, out, b, self.L, c["use_flex_spec_target"], P.lpart, P.dout)
+        ops.loss_finalize(P.lpart, n, 1.0, lo, 2)
+        dec.backward(D, styles, P.m_dec[1], P.dout, P.dstyles)
+        enc.backward(E, P.spec, P.m_enc[2], P.dstyles)
+        self._adam(P, "reconstruction", self._slab_notes)
+        # ---- phase D: mutual information (:175-186)
+        self._begin_phase(record)
+        enc.forward(E, P.spec, P.m_enc[3])          # result unused by the reference too (BN stats + RNG)
+        z_s = tape.view(P.z_sample, b, ns)
+        out = dec.forward(D, z_s, P.m_dec[2])
+        z_rec = enc.forward(E, out, P.m_enc[4])
+        n = ops.mse_fwd_bwd(z_rec, z_s, b * ns, P.lpart, P.dstyles)
+        ops.loss_finalize(P.lpart, n, 1.0, lo, 3, 5)
+        enc.backward(E, out, P.m_enc[4], P.dstyles, P.dspec)
+        dec.backward(D, z_s, P.m_dec[2], P.dspec, None)
+        self._adam(P, "mutual_info", self._slab_notes)
+        # ---- phase E: smoothness (:189-200); encoder gradients are discarded by the reference
+        if smooth:
+            self._begin_phase(record)
+            styles = enc.forward(E, P.spec, P.m_enc[5])
+            out = dec.forward(D, styles, P.m_dec[3])
+            n = ops.smooth_loss_fwd_bwd(out, b, self.L, self.taps, P.lpart, P.dout)
+            ops.loss_finalize(P.lpart, n, 1.0, lo, 4)
+            dec.backward(D, styles, P.m_dec[3], P.dout, None)
+            self._adam(P, "smoothness", self._slab_notes)
+        self._slab_notes = None
+
+    @_on_stream
+    def step(self, b, smooth=True):
+        """Run one training step on the next ``b`` rows of the epoch permutation."""
+        P = self.plan(b)
+        if self.rng_mode == "host":
+            P.tape.draws, saved = (P.tape.draws if smooth else P.tape.draws[:P.n_draws_no_smooth]), P.tape.draws
+            P.tape.fill_host()
+            P.tape.draws = saved
+        key = bool(smooth)
+        if key not in P.graphs:
+            # first call: eager emission (records slab counts, sets kernel attributes) ...
+            self.emit_step(P, smooth, record=True)
+            P.graphs[key] = None
+            return
+        if self.use_graph and P.graphs[key] is None:
+            # ... second call: capture; the capture itself does not execute, so launch it right away
+            bn_saved = dict(self.bn_counts)
+            g = ops.Graph()
+            g.begin()
+            self.emit_step(P, smooth, record=False)
+            g.end()
+            self.bn_counts = bn_saved
+            P.graphs[key] = g
+        if self.use_graph:
+            P.graphs[key].launch()
+            self._count_bn_step(smooth)
+        else:
+            self.emit_step(P, smooth, record=False)
+
+    def phase_gradient(self, P, name):
+        """Flat gradient (fixed-order slab sum) of optimizer ``name``'s arena range -- what the
+        fused Adam kernel consumes.  For tests and debugging."""
+        o = self.opts[name]
+        seg = P.seg[name][o.lo // 64:o.hi // 64].long().repeat_interleave(64)
+        g = torch.zeros(o.hi - o.lo, device=self.device)
+        for s in range(int(seg.max())):
+            g += torch.where(seg > s, self.G[s, o.lo:o.hi], torch.zeros_like(g))
+        return g
+
+    @_on_stream
+    def load_optimizer_state(self, name, params, torch_optimizer):
+        """Copy ``exp_avg`` / ``exp_avg_sq`` / ``step`` of a ``torch.optim.Adam(W)`` whose
+        parameters correspond, in order, to ``params`` (this engine's parameters)."""
+        o = self.opts[name]
+        theirs = [p for grp in torch_optimizer.param_groups for p in grp["params"]]
+        assert len(theirs) == len(params)
+        step = 0
+        for mine, other in zip(params, theirs):
+            st = torch_optimizer.state.get(other, {})
+            off = self.arena.off(mine) - o.lo
+            n = mine.numel()
+            if st:
+                o.m[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                o.v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                step = int(st["step"])
+            else:
+                o.m[off:off + n].zero_()
+                o.v[off:off + n].zero_()
+        self.steps_dev[o.index] = step
+        for grp in torch_optimizer.param_groups:
+            o.lr = float(grp["lr"])
+        o.push()
+
+    def _count_bn_step(self, smooth):
+        n_enc, n_dec = (6, 4) if smooth else (5, 3)
+        for bn in self.enc.bn_modules:
+            self.bn_counts[id(bn)] = self.bn_counts.get(id(bn), 0) + n_enc
+        for bn in self.dec.bn_modules:
+            self.bn_counts[id(bn)] = self.bn_counts.get(id(bn), 0) + n_dec
+
+    @_on_stream
+    def sync_bn_counters(self):
+        """Write ``num_batches_tracked`` (host-side count of train-mode forwards) into the modules."""
+        for net in (self.enc, self.dec):
+            for bn in net.bn_modules:
+                bn.num_batches_tracked.fill_(self.bn_counts.get(id(bn), 0))
+
+    @_on_stream
+    def losses(self):
+        v = self.loss_out.cpu().tolist()
+        return {k: v[i] for k, i in LOSS_SLOTS.items()}
+
+    # -- validation (trainer.py:206-268): eval-mode forward of the whole validation set
+    @_on_stream
+    def validate(self, val_spec, val_aux, rng_host=True):
+        c, dev, ns = self.cfg, self.device, self.nstyle
+        nv, bc = val_spec.shape[0], c["batch_size"]
+        key = ("val", nv)
+        if key not in self.plans:
+            V = StepPlan()
+            V.enc, V.dec = self.enc.alloc(nv), self.dec.alloc(nv)
+            V.enc2 = self.enc.alloc(nv)
+            V.disc = self.disc.alloc(bc, nv)
+            V.tape = Tape()
+            V.z_sample = V.tape.slot(nv * ns, 0)
+            V.tape.draw("normal", V.z_sample, (nv, ns))
+            V.sl_disc = self.disc.tape_slots(V.tape, bc, nv, train=False)
+            V.tape.finalize(dev)
+            V.rank_work = torch.empty(ops.rank_loss_work_bytes(nv, self.n_aux), dtype=torch.uint8, device=dev)
+            V.lpart = torch.zeros(RAAE_MAX_PARTS, dtype=torch.float64, device=dev)
+            V.out = torch.zeros(8, device=dev)
+            self.plans[key] = V
+        V = self.plans[key]
+        self.tape = V.tape
+        if self.rng_mode == "host":
+            torch.empty((), dtype=torch.int64).random_()     # the val DataLoader iterator's _base_seed draw
+            V.tape.fill_host()
+        else:
+            ops.rng_fill(V.tape.buf, V.tape.seg_desc, V.tape.seg_scale, len(V.tape.segs), V.tape.total,
+                         self.seed ^ 0x5EED, self.rng_counter)
+        z = self.enc.forward(V.enc, val_spec, None, train=False)
+        out = self.dec.forward(V.dec, z, None, train=False)
+        n = ops.recon_loss_fwd_bwd(val_spec, out, nv, self.L, False, V.lpart, None)
+        ops.loss_finalize(V.lpart, n, 1.0, V.out, 2)
+        ops.rank_loss_fwd_bwd(val_aux, self.n_aux, z, ns, nv, self.n_aux, c["kendall_activation"], V.rank_work,
+                              V.out[1:2], None)
+        n = ops.smooth_loss_fwd_bwd(out, nv, self.L, self.taps, V.lpart, None)
+        ops.loss_finalize(V.lpart, n, 1.0, V.out, 4)
+        z_s = V.tape.view(V.z_sample, nv, ns)
+        out2 = self.dec.forward(V.dec, z_s, None, train=False)
+        z_rec = self.enc.forward(V.enc2, out2, None, train=False)
+        n = ops.mse_fwd_bwd(z_rec, z_s, nv * ns, V.lpart, None)
+        ops.loss_finalize(V.lpart, n, 1.0, V.out, 3)
+        self.disc.forward_backward(V.disc, V.sl_disc, z, V.out[0:1], train=False)
+        v = V.out.cpu().tolist()
+        return z, {k: v[i] for k, i in LOSS_SLOTS.items() if k != "mi_accum"}
