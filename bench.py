@@ -1,0 +1,189 @@
+#!/usr/bin/env python
+"""Benchmark of the RankAAE training-step hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--ae-form compact|FC] [--batch 256]
+
+One "step" = the reference's five-phase update (adversarial, rank, reconstruction,
+mutual-information, smoothness: 6 encoder + 4 decoder forwards, 5 backwards, 5 AdamW
+updates; ``sc/clustering/trainer.py:103-204``) on one batch of 256 synthetic 256-point
+spectra drawn from a device-resident 7000-row dataset (BASELINE.json ``configs[1]``).
+Rank 0 prints ONE JSON line.  ``value`` = batch-256 steps per second summed over all
+ranks (weak scaling: every GPU steps its own 256-row shard of a 256*N global batch and
+the five gradient arenas are averaged over RCCL).  The line also carries:
+  roofline      the dominant kernel of this workload: algorithmic bytes / HIP-event time
+  cpu_baseline  the CPU oracle (PyTorch fp32 autograd restatement of the reference) timed on
+                this box's host cores: 1 thread + anomaly detection on, as the reference ships
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+BASE_CFG = dict(  # example/fix_config.yaml of the reference; only trials/batch_size/ae_form/max_epoch change
+    trials=1, timeout=10, verbose=False, max_epoch=2000, batch_size=256,
+    gradient_reversal=True, alpha_flat_step=739, alpha_limit=0.7172, decoder_activation="Softplus",
+    dis_beta=1.1, dis_dropout_rate=0.056, dis_noise=0.56, gen_beta=1.1, n_aux=5, nstyle=6, ae_form="compact",
+    dim_in=256, dim_out=256, n_layers=5, FC_discriminator_layers=3, use_cnn_discriminator=False,
+    dropout_rate=0.04, sch_factor=0.1, sch_patience=100, lr_base=0.001, lr_ratio_Corr=10, lr_ratio_Mutual=1,
+    lr_ratio_Reconn=10, lr_ratio_Smooth=1, lr_ratio_dis=1, lr_ratio_gen=10, optimizer_name="AdamW",
+    spec_noise=0.02, use_flex_spec_target=True, weight_decay=0.01, kendall_activation=True, epoch_stop_smooth=1500)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def build_models(cfg, seed):
+    from rankaae_amd import model as pm
+    torch.manual_seed(seed)
+    cls = pm.AE_CLS_DICT[cfg["ae_form"]]
+    enc = cls["encoder"](nstyle=cfg["nstyle"], dropout_rate=cfg["dropout_rate"], dim_in=cfg["dim_in"],
+                         n_layers=cfg["n_layers"])
+    dec = cls["decoder"](nstyle=cfg["nstyle"], dropout_rate=cfg["dropout_rate"],
+                         last_layer_activation=cfg["decoder_activation"], dim_out=cfg["dim_out"],
+                         n_layers=cfg["n_layers"])
+    dis = pm.DiscriminatorFC(nstyle=cfg["nstyle"], dropout_rate=cfg["dis_dropout_rate"], noise=cfg["dis_noise"],
+                             layers=cfg["FC_discriminator_layers"])
+    return enc, dec, dis
+
+
+def cpu_baseline(cfg, spec, aux, budget_s):
+    """The oracle (kind "port") on this box's host cores, 1 thread, anomaly detection ON
+    (how ``train_sc`` runs the reference: train_sc.py:68-70, trainer.py:11); also times it with
+    anomaly detection off.  Bounded sample: whole steps until ``budget_s`` seconds are used."""
+    from oracle import ref_train
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    out = {}
+    for anomaly, share in ((True, 0.65), (False, 0.35)):
+        torch.manual_seed(1234)
+        tr = ref_train.OracleTrainer(spec, aux, cfg)
+        for m in (tr.encoder, tr.decoder, tr.discriminator):
+            m.train()
+        perm = ref_train.epoch_permutation(len(tr.train_spec)).numpy()
+        bs = cfg["batch_size"]
+        prev = torch.is_anomaly_enabled()
+        torch.autograd.set_detect_anomaly(anomaly)
+        t0, n = time.perf_counter(), 0
+        while True:
+            rows = perm[(n % 19) * bs:(n % 19 + 1) * bs]
+            tr.train_step(torch.tensor(tr.train_spec[rows], dtype=torch.float32),
+                          torch.tensor(tr.train_aux[rows], dtype=torch.float32), 0.3, 0)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s * share and n >= 3:
+                break
+        torch.autograd.set_detect_anomaly(prev)
+        out[anomaly] = (n / el, n, el)
+    torch.set_num_threads(nthreads)
+    v, n, el = out[True]
+    return {"value": round(v, 3), "unit": "steps/s", "cores": 1, "kind": "port",
+            "sample": f"{n} steps of the same workload in {el:.1f} s, 1 thread, autograd anomaly detection on "
+                      f"(as the reference ships); anomaly off: {out[False][0]:.3f} steps/s",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--ae-form", default=os.environ.get("RANKAAE_BENCH_AE_FORM", "FC"))
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--rows", type=int, default=7000)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-oracle timing (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from rankaae_amd.engine import StepEngine
+    from rankaae_amd.synthetic import make_spectra
+    from rankaae_amd.dataloader import split_counts
+
+    cfg = dict(BASE_CFG)
+    cfg.update(ae_form=args.ae_form, batch_size=args.batch)
+    spec, aux, _ = make_spectra(args.rows, cfg["dim_in"], cfg["n_aux"], seed=0)
+    n_train = split_counts(args.rows)[0]
+    enc, dec, dis = build_models(cfg, 1234)
+    eng = StepEngine(enc, dec, dis, cfg, dev, rng_mode="philox", seed=1234 + rank, use_graph=not args.no_graph,
+                     world_size=world, rank=rank)
+    # every rank holds the whole training split in HBM; with N ranks a global batch is N*batch rows and
+    # rank r steps rows [r*batch, (r+1)*batch) of it (same permutation on all ranks)
+    eng.set_data(spec[:n_train], aux[:n_train])
+    b = args.batch
+    full_batches = n_train // (b * world)
+    if full_batches < 1:
+        raise SystemExit("dataset too small for one global batch")
+    gen = torch.Generator().manual_seed(7)
+    state = {"i": 0}
+
+    def one_step():
+        if state["i"] % full_batches == 0:
+            perm = torch.randperm(n_train, generator=gen)
+            eng.set_epoch(perm, 0.7172, start=rank * b, stride=world * b)
+        eng.step(b, smooth=True)
+        state["i"] += 1
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 3)):     # >= 3: eager emission, graph capture, first replay
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    losses = eng.losses()
+    finite = all(np.isfinite(v) for v in losses.values())
+
+    if rank == 0:
+        value = world * args.steps / dt
+        line = {
+            "metric": "training steps/sec (batch=256, 256-pt spectra)", "value": round(value, 2),
+            "unit": "steps/s (five-phase steps on 256-row batches, summed over ranks)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: {args.rows}x{cfg['dim_in']} synthetic spectra (train split "
+                                   f"{n_train}), batch {b}/GPU, ae_form={cfg['ae_form']}, nstyle={cfg['nstyle']}, "
+                                   f"n_aux={cfg['n_aux']}, AdamW, 5 phases incl. smoothness",
+                       "global_batch": b * world, "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
+                       "rng": "philox tape (device)"},
+            "losses_finite": finite, "last_losses": {k: round(v, 6) for k, v in losses.items()},
+        }
+        if not args.no_roofline:
+            line["roofline"] = eng.roofline_probe(b, HBM_PEAK_GBS)
+        if args.cpu_budget > 0:
+            line["cpu_baseline"] = cpu_baseline(cfg, spec, aux, args.cpu_budget)
+            line["speedup_vs_cpu_baseline"] = round(value / line["cpu_baseline"]["value"], 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

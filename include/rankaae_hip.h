@@ -149,6 +149,78 @@ int raae_gather_batch(const float* spec, const float* aux, const long* idx, cons
  *   decoupled=1 => AdamW (p *= 1-lr*wd), 0 => Adam (g += wd*p). */
 int raae_adam_step(float* p, float* m, float* v, const float* g_slabs, long slab_stride, const unsigned char* seg_nslab,
                    long n, const double* hyper, const int* step, int decoupled, void* stream);
+/* ====================== 1-D convolutional networks (ae_form: compact) ======================
+ * Activations are [B][C][L] fp32, stored RAW (pre-activation); what a consumer sees is a *view*:
+ *     value = mask * BatchNorm( PReLU(raw, slope_c) )          (each stage optional)
+ * so PReLU, BatchNorm(affine=False) and Dropout never make a pass over memory of their own. */
+typedef struct {
+    const float* raw;       /* [B][C][L] */
+    const float* slope;     /* [C] PReLU slopes or NULL */
+    raae_bn_t bn;           /* statistics over (B, L) per channel, valid iff has_bn */
+    int has_bn;
+    const float* mask;      /* [B][C][L] dropout scale or NULL */
+} raae_view_t;
+
+/* How dL/d(raw output) of a layer is obtained from what its consumer left behind:
+ *   dA   = has_bn ? rstd_c * (g - mean_c(g) - y * mean_c(g*y)) : g,   y = (u - mu_c) * rstd_c
+ *   dRaw = dA * PReLU'(raw)     (slope != NULL)   |  dA * (1 - exp(-2 out))  (act == softplus, raw = out)
+ * `u` is the tensor the BatchNorm normalised: NULL means u = PReLU(raw) (own output), else e.g. the
+ * three-way block sum Y.  dslope_c = sum dA * raw [raw <= 0]. */
+typedef struct {
+    const float* g;               /* [B][C][L] */
+    const double* g_partials;     /* [g_nparts][C][2] {sum g, sum g*y}; needed iff has_bn */
+    int g_nparts;
+    const float* u;
+    raae_bn_t bn;
+    int has_bn;
+    const float* raw;
+    const float* slope;
+    int act;                      /* RAAE_OUT_RAW | RAAE_OUT_SOFTPLUS | RAAE_OUT_RELU */
+} raae_grad_t;
+
+typedef struct {
+    int Cin, Lin, Cout, Lout, K, stride, pad, pad_replicate, groups, transposed;
+} raae_conv_t;   /* transposed => ConvTranspose1d with K == stride, pad 0 (the only form the reference uses) */
+
+/* nn.Conv1d / nn.ConvTranspose1d forward over a view (EncodingBlock / DecodingBlock convs, reference
+ * sc/clustering/model.py:33-38,51,59,114-119,133,140,461).  Weight layouts are torch's:
+ * Conv1d [Cout][Cin/groups][K], ConvTranspose1d [Cin][Cout/groups][K].
+ * stats_kind: RAAE_OUT_RAW none | RAAE_OUT_STATS_PRELU of PReLU(out,out_slope) | RAAE_OUT_STATS_RAW;
+ * act: RAAE_OUT_RAW | RAAE_OUT_SOFTPLUS | RAAE_OUT_RELU applied to what is stored. */
+int raae_conv_fwd(const raae_view_t* in, int B, const raae_conv_t* cv, const float* w, const float* bias, float* out,
+                  int stats_kind, const float* out_slope, double* out_partials, int* out_nparts, int act, void* stream);
+/* dL/d(view value of the input) (= dValue * mask, i.e. w.r.t. the BatchNorm output).  accumulate != 0 adds
+ * to din; din_partials (may be NULL) receives {sum din, sum din*y_in} of the FINAL din (after accumulation). */
+int raae_conv_bwd_data(const raae_grad_t* go, int B, const raae_conv_t* cv, const float* w, const raae_view_t* in,
+                       float* din, int accumulate, double* din_partials, int* din_nparts, void* stream);
+/* parameter gradients: dw, dbias (same layouts as w/bias) and dslope [Cout] (may be NULL); final values,
+ * one workgroup per element, fixed-order tree => deterministic. */
+int raae_conv_bwd_weight(const raae_grad_t* go, int B, const raae_conv_t* cv, const raae_view_t* in,
+                         float* dw, float* dbias, float* dslope, void* stream);
+
+/* nn.Linear applied along the LENGTH axis of [B][C][Lin] -> [B][C][E] (excitation fc1 / fc2, reference
+ * model.py:44-47,89-93,125-128,164-167); out_slope / statistics are per CHANNEL c (PReLU on dim 1). */
+int raae_lenlin_fwd(const raae_view_t* in, int B, int C, int Lin, const float* w, const float* bias, int E, float* out,
+                    int stats_kind, const float* out_slope, double* out_partials, int* out_nparts, void* stream);
+int raae_lenlin_bwd_data(const raae_grad_t* go, int B, int C, int E, const float* w, const raae_view_t* in, int Lin,
+                         float* din, int accumulate, double* din_partials, int* din_nparts, void* stream);
+int raae_lenlin_bwd_weight(const raae_grad_t* go, int B, int C, int E, const raae_view_t* in, int Lin,
+                           float* dw, float* dbias, float* dslope, void* stream);
+
+/* Block output: y = view_a + view_b + view_c (reference model.py:99,173), statistics of y for the next BN. */
+int raae_sum3_fwd(const raae_view_t* a, const raae_view_t* b, const raae_view_t* c, int B, int C, int L, float* y,
+                  double* out_partials, int* out_nparts, void* stream);
+/* dRaw of a grad spec written (accumulate = 0) or added (accumulate != 0) to `draw` -- the identity
+ * shortcut of a block without conv_short (model.py:83), and the gradient handed to a dense layer;
+ * dslope (may be NULL): final PReLU-slope gradient [C]. */
+int raae_grad_materialize(const raae_grad_t* go, int B, int C, int L, float* draw, int accumulate, float* dslope,
+                          void* stream);
+
+/* Data parallel (replaces the reference's ipyparallel trial farm, sc/cmd/train_sc.py:25-45, per the
+ * north star): out[i] = fixed-order sum of the slabs of element i -- the flat gradient that is then
+ * averaged across ranks with one RCCL all-reduce per phase and fed to raae_adam_step as a single slab. */
+int raae_slab_reduce(const float* g_slabs, long slab_stride, const unsigned char* seg_nslab, long n, float* out,
+                     void* stream);
 /* once per training step: steps[i] += 1 for every bit i set in mask; rng_counter[0] += 1;
  * cursor[0] += cursor_inc (epoch row cursor of raae_gather_batch) */
 int raae_step_tick(int* steps, int n, unsigned mask, unsigned long long* rng_counter, int* cursor, int cursor_inc,

@@ -21,6 +21,23 @@ class BnT(C.Structure):
                 ("momentum", C.c_float), ("eps", C.c_float), ("update_running", C.c_int)]
 
 
+class ViewT(C.Structure):
+    """``raae_view_t``"""
+    _fields_ = [("raw", C.c_void_p), ("slope", C.c_void_p), ("bn", BnT), ("has_bn", C.c_int), ("mask", C.c_void_p)]
+
+
+class GradT(C.Structure):
+    """``raae_grad_t``"""
+    _fields_ = [("g", C.c_void_p), ("g_partials", C.c_void_p), ("g_nparts", C.c_int), ("u", C.c_void_p),
+                ("bn", BnT), ("has_bn", C.c_int), ("raw", C.c_void_p), ("slope", C.c_void_p), ("act", C.c_int)]
+
+
+class ConvT(C.Structure):
+    """``raae_conv_t``"""
+    _fields_ = [(n, C.c_int) for n in ("Cin", "Lin", "Cout", "Lout", "K", "stride", "pad", "pad_replicate",
+                                       "groups", "transposed")]
+
+
 class HipLibraryMissing(RuntimeError):
     pass
 
@@ -32,6 +49,7 @@ class HipCallError(RuntimeError):
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
 _PI = C.POINTER(C.c_int)
 _PB = C.POINTER(BnT)
+_PV, _PG, _PC = C.POINTER(ViewT), C.POINTER(GradT), C.POINTER(ConvT)
 
 # name -> (restype, argtypes); every symbol include/rankaae_hip.h declares
 SIGNATURES = {
@@ -51,6 +69,15 @@ SIGNATURES = {
     "raae_loss_finalize": (_I, [_P, _I, _F, _P, _I, _I, _P]),
     "raae_gather_batch": (_I, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P]),
     "raae_adam_step": (_I, [_P, _P, _P, _P, _L, _P, _L, _P, _P, _I, _P]),
+    "raae_conv_fwd": (_I, [_PV, _I, _PC, _P, _P, _P, _I, _P, _P, _PI, _I, _P]),
+    "raae_conv_bwd_data": (_I, [_PG, _I, _PC, _P, _PV, _P, _I, _P, _PI, _P]),
+    "raae_conv_bwd_weight": (_I, [_PG, _I, _PC, _PV, _P, _P, _P, _P]),
+    "raae_lenlin_fwd": (_I, [_PV, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P, _PI, _P]),
+    "raae_lenlin_bwd_data": (_I, [_PG, _I, _I, _I, _P, _PV, _I, _P, _I, _P, _PI, _P]),
+    "raae_lenlin_bwd_weight": (_I, [_PG, _I, _I, _I, _PV, _I, _P, _P, _P, _P]),
+    "raae_sum3_fwd": (_I, [_PV, _PV, _PV, _I, _I, _I, _P, _P, _PI, _P]),
+    "raae_grad_materialize": (_I, [_PG, _I, _I, _I, _P, _I, _P, _P]),
+    "raae_slab_reduce": (_I, [_P, _L, _P, _L, _P, _P]),
     "raae_step_tick": (_I, [_P, _I, C.c_uint, _P, _P, _I, _P]),
     "raae_rng_fill": (_I, [_P, _P, _P, _I, _L, C.c_ulonglong, _P, _P]),
     "raae_graph_begin": (_I, [_P]),

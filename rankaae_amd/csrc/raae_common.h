@@ -50,20 +50,54 @@ __device__ __forceinline__ float softplus2(float x) {
     return bx > 20.f ? x : 0.5f * log1pf(expf(bx));
 }
 
-// Reduce BatchNorm partial sums -> mean / rstd for C channels into shared arrays.
-// Every thread of the block must call it; ends with __syncthreads().
+// Fixed-order reduction of per-workgroup partials [nparts][C][2] (doubles) into per-channel
+// totals, spread over the first 256 threads: thread (c, j) sums parts j, j+J, ... (independent
+// loads, all in flight together), then thread c adds the J slices in order.  C <= 256.
+// Results land in LDS arrays tot_s / tot_q (doubles, >= C).  Ends with __syncthreads().
+__device__ __forceinline__ void reduce_partials(const double* partials, int nparts, int C, double* tot_s,
+                                                double* tot_q) {
+    __shared__ double scr_s[256], scr_q[256];
+    int Cp = 1;
+    while (Cp < C) Cp <<= 1;
+    const int J = 256 / Cp;                 // >= 1 because C <= 256
+    const int t = threadIdx.x;
+    if (t < 256) {
+        const int c = t & (Cp - 1), j = t / Cp;
+        double s = 0.0, q = 0.0;
+        if (c < C) {
+            const double2* p = reinterpret_cast<const double2*>(partials) + c;
+            int i = j;
+            for (; i + 3 * J < nparts; i += 4 * J) {
+                const double2 v0 = p[(size_t)i * C], v1 = p[(size_t)(i + J) * C];
+                const double2 v2 = p[(size_t)(i + 2 * J) * C], v3 = p[(size_t)(i + 3 * J) * C];
+                s += v0.x; q += v0.y; s += v1.x; q += v1.y; s += v2.x; q += v2.y; s += v3.x; q += v3.y;
+            }
+            for (; i < nparts; i += J) { const double2 v = p[(size_t)i * C]; s += v.x; q += v.y; }
+        }
+        scr_s[t] = s; scr_q[t] = q;
+    }
+    __syncthreads();
+    if (t < C) {
+        double s = 0.0, q = 0.0;
+        for (int j = 0; j < J; ++j) { s += scr_s[j * Cp + t]; q += scr_q[j * Cp + t]; }
+        tot_s[t] = s; tot_q[t] = q;
+    }
+    __syncthreads();
+}
+
+// BatchNorm statistics for a consumer: mean / rstd of C channels into LDS arrays.
+// Every thread of the block must call it (blockDim >= 256 or C <= blockDim); ends with a barrier.
 // Train mode: biased variance for normalisation; block 0 (when update_running) applies
 // running = (1-m) running + m * {mean, unbiased var}  (torch.nn.BatchNorm1d semantics).
 __device__ __forceinline__ void bn_prologue(const raae_bn_t& bn, int C, float* s_mean, float* s_rstd,
                                             bool is_block0) {
     if (bn.partials != nullptr) {
+        __shared__ double tot_s[256], tot_q[256];
+        reduce_partials(bn.partials, bn.nparts, C, tot_s, tot_q);
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
-            double s = 0.0, q = 0.0;
-            const double* p = bn.partials + 2 * (size_t)c;
-            for (int i = 0; i < bn.nparts; ++i) { s += p[0]; q += p[1]; p += 2 * (size_t)C; }
             const double n = (double)bn.count;
-            const double mean = s / n;
-            double var = q / n - mean * mean;
+            const double mean = tot_s[c] / n;
+            double var = tot_q[c] / n - mean * mean;
             if (var < 0.0) var = 0.0;
             s_mean[c] = (float)mean;
             s_rstd[c] = (float)(1.0 / sqrt(var + (double)bn.eps));
@@ -85,12 +119,11 @@ __device__ __forceinline__ void bn_prologue(const raae_bn_t& bn, int C, float* s
 // Column sums {sum g, sum g*y} partials -> per-channel mean terms for BN backward.
 __device__ __forceinline__ void bnbwd_prologue(const double* partials, int nparts, int C, float count,
                                                float* s_m1, float* s_m2) {
+    __shared__ double tot_s[256], tot_q[256];
+    reduce_partials(partials, nparts, C, tot_s, tot_q);
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        double s = 0.0, q = 0.0;
-        const double* p = partials + 2 * (size_t)c;
-        for (int i = 0; i < nparts; ++i) { s += p[0]; q += p[1]; p += 2 * (size_t)C; }
-        s_m1[c] = (float)(s / (double)count);
-        s_m2[c] = (float)(q / (double)count);
+        s_m1[c] = (float)(tot_s[c] / (double)count);
+        s_m2[c] = (float)(tot_q[c] / (double)count);
     }
     __syncthreads();
 }

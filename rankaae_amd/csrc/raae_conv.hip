@@ -1,0 +1,574 @@
+// 1-D convolutional encoder/decoder kernels (ae_form: compact): Conv1d / ConvTranspose1d /
+// length-axis Linear / block sum, forward and backward, over "views" (raw tensor + PReLU +
+// BatchNorm + dropout scale applied on load) -- reference sc/clustering/model.py:24-174, 264-295,
+// 430-474 and their autograd.
+//
+// Layout: activations [B][C][L] fp32 contiguous (coalesced along L).  C <= 64, L <= 512.
+// Mapping: a workgroup owns ONE channel and a contiguous slice of the (b, l) index space, so
+// BatchNorm partial sums are per-workgroup scalars (fixed order, no atomics); parameter
+// gradients are produced one workgroup per element as final values.
+#include "raae_common.h"
+
+namespace {
+
+using raae::prelu;
+
+#define CV_MAXC 64
+
+struct ViewStats { float mean[CV_MAXC]; float rstd[CV_MAXC]; };
+struct GradStats { float mean[CV_MAXC]; float rstd[CV_MAXC]; float m1[CV_MAXC]; float m2[CV_MAXC]; };
+
+__device__ __forceinline__ void view_prologue(const raae_view_t& v, int C, ViewStats* st, bool block0) {
+    if (v.has_bn) raae::bn_prologue(v.bn, C, st->mean, st->rstd, block0);
+}
+__device__ __forceinline__ void grad_prologue(const raae_grad_t& g, int C, GradStats* st) {
+    if (g.has_bn) {
+        raae::bn_prologue(g.bn, C, st->mean, st->rstd, false);
+        raae::bnbwd_prologue(g.g_partials, g.g_nparts, C, g.bn.count, st->m1, st->m2);
+    }
+}
+
+// value of a view at flat element idx of channel c
+__device__ __forceinline__ float view_at(const raae_view_t& v, const ViewStats* st, int c, size_t idx) {
+    float x = v.raw[idx];
+    if (v.slope) x = prelu(x, v.slope[c]);
+    if (v.has_bn) x = (x - st->mean[c]) * st->rstd[c];
+    if (v.mask) x *= v.mask[idx];
+    return x;
+}
+// BatchNorm output of a view (before the dropout scale) -- "y" of the BN backward formula
+__device__ __forceinline__ float view_y(const raae_view_t& v, const ViewStats* st, int c, size_t idx) {
+    float x = v.raw[idx];
+    if (v.slope) x = prelu(x, v.slope[c]);
+    return (x - st->mean[c]) * st->rstd[c];
+}
+// dL/d raw at element idx of channel c; *da = gradient w.r.t. the PReLU output (for dslope)
+__device__ __forceinline__ float grad_at(const raae_grad_t& g, const GradStats* st, int c, size_t idx, float* da_out,
+                                         float* raw_out) {
+    const float gv = g.g[idx];
+    const float raw = g.raw ? g.raw[idx] : 0.f;
+    float da = gv;
+    if (g.has_bn) {
+        const float u = g.u ? g.u[idx] : (g.slope ? prelu(raw, g.slope[c]) : raw);
+        const float y = (u - st->mean[c]) * st->rstd[c];
+        da = st->rstd[c] * (gv - st->m1[c] - y * st->m2[c]);
+    }
+    float dr = da;
+    if (g.slope) dr = raw > 0.f ? da : da * g.slope[c];
+    else if (g.act == RAAE_OUT_SOFTPLUS) dr = da * (1.f - expf(-2.f * raw));
+    else if (g.act == RAAE_OUT_RELU) dr = raw > 0.f ? da : 0.f;
+    if (da_out) *da_out = da;
+    if (raw_out) *raw_out = raw;
+    return dr;
+}
+
+// slice of the (b, l) space owned by this workgroup: [lo, hi)
+__device__ __forceinline__ void slice_range(long total, int nsl, int sl, long* lo, long* hi) {
+    const long per = (total + nsl - 1) / nsl;
+    *lo = (long)sl * per;
+    *hi = *lo + per < total ? *lo + per : total;
+    if (*lo > total) *lo = total;
+}
+
+// ------------------------------------------------------------------ conv forward
+struct ConvFwdArgs {
+    raae_view_t in; int B; raae_conv_t cv; const float* w; const float* bias; float* out;
+    int stats_kind; const float* out_slope; double* out_partials; int act; int nsl;
+};
+
+__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
+    __shared__ ViewStats vs;
+    __shared__ float s_w[CV_MAXC * 16];
+    __shared__ double shd[16];
+    const raae_conv_t& cv = a.cv;
+    const int co = blockIdx.x % cv.Cout, sl = blockIdx.x / cv.Cout;
+    const int cig = cv.Cin / cv.groups, cog = cv.Cout / cv.groups;
+    const int grp = co / cog, col = co - grp * cog;
+    view_prologue(a.in, cv.Cin, &vs, blockIdx.x == 0);
+    // weights of this output channel -> LDS as [ci_local][t]
+    for (int i = threadIdx.x; i < cig * cv.K; i += 256) {
+        const int cil = i / cv.K, t = i - cil * cv.K;
+        s_w[i] = cv.transposed ? a.w[((size_t)(grp * cig + cil) * cog + col) * cv.K + t]
+                               : a.w[((size_t)co * cig + cil) * cv.K + t];
+    }
+    __syncthreads();
+    const float bias = a.bias[co];
+    const float oslope = (a.stats_kind == RAAE_OUT_STATS_PRELU) ? a.out_slope[co] : 1.f;
+    long lo, hi;
+    slice_range((long)a.B * cv.Lout, a.nsl, sl, &lo, &hi);
+    double s_acc = 0.0, q_acc = 0.0;
+    for (long i = lo + threadIdx.x; i < hi; i += 256) {
+        const int b = (int)(i / cv.Lout), l = (int)(i - (long)b * cv.Lout);
+        float acc = bias;
+        for (int cil = 0; cil < cig; ++cil) {
+            const int ci = grp * cig + cil;
+            const size_t base = ((size_t)b * cv.Cin + ci) * cv.Lin;
+            if (cv.transposed) {
+                const int li = l / cv.stride, t = l - li * cv.stride;
+                acc += s_w[cil * cv.K + t] * view_at(a.in, &vs, ci, base + li);
+            } else {
+                for (int t = 0; t < cv.K; ++t) {
+                    int p = l * cv.stride + t - cv.pad;
+                    if (p < 0 || p >= cv.Lin) {
+                        if (!cv.pad_replicate) continue;
+                        p = p < 0 ? 0 : cv.Lin - 1;
+                    }
+                    acc += s_w[cil * cv.K + t] * view_at(a.in, &vs, ci, base + p);
+                }
+            }
+        }
+        float o = acc;
+        if (a.act == RAAE_OUT_SOFTPLUS) o = raae::softplus2(acc);
+        else if (a.act == RAAE_OUT_RELU) o = fmaxf(acc, 0.f);
+        a.out[((size_t)b * cv.Cout + co) * cv.Lout + l] = o;
+        if (a.stats_kind != RAAE_OUT_RAW) {
+            const float v = (a.stats_kind == RAAE_OUT_STATS_PRELU) ? prelu(acc, oslope) : acc;
+            s_acc += (double)v; q_acc += (double)v * (double)v;
+        }
+    }
+    if (a.stats_kind != RAAE_OUT_RAW) {
+        const double s = raae::block_sum(s_acc, shd);
+        const double q = raae::block_sum(q_acc, shd);
+        if (threadIdx.x == 0) {
+            double* p = a.out_partials + ((size_t)sl * cv.Cout + co) * 2;
+            p[0] = s; p[1] = q;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ conv backward (data)
+struct ConvBwdDataArgs {
+    raae_grad_t go; int B; raae_conv_t cv; const float* w; raae_view_t in; float* din; int accumulate;
+    double* din_partials; int nsl;
+};
+
+__global__ __launch_bounds__(256) void conv_bwd_data_kernel(ConvBwdDataArgs a) {
+    __shared__ ViewStats vs;
+    __shared__ GradStats gs;
+    __shared__ float s_w[CV_MAXC * 16];          // [co_local][t] for this input channel
+    __shared__ double shd[16];
+    const raae_conv_t& cv = a.cv;
+    const int ci = blockIdx.x % cv.Cin, sl = blockIdx.x / cv.Cin;
+    const int cig = cv.Cin / cv.groups, cog = cv.Cout / cv.groups;
+    const int grp = ci / cig, cil = ci - grp * cig;
+    view_prologue(a.in, cv.Cin, &vs, false);
+    grad_prologue(a.go, cv.Cout, &gs);
+    for (int i = threadIdx.x; i < cog * cv.K; i += 256) {
+        const int col = i / cv.K, t = i - col * cv.K;
+        s_w[i] = cv.transposed ? a.w[((size_t)ci * cog + col) * cv.K + t]
+                               : a.w[((size_t)(grp * cog + col) * cig + cil) * cv.K + t];
+    }
+    __syncthreads();
+    long lo, hi;
+    slice_range((long)a.B * cv.Lin, a.nsl, sl, &lo, &hi);
+    double s_acc = 0.0, q_acc = 0.0;
+    for (long i = lo + threadIdx.x; i < hi; i += 256) {
+        const int b = (int)(i / cv.Lin), li = (int)(i - (long)b * cv.Lin);
+        float acc = 0.f;
+        for (int col = 0; col < cog; ++col) {
+            const int co = grp * cog + col;
+            const size_t obase = ((size_t)b * cv.Cout + co) * cv.Lout;
+            if (cv.transposed) {
+                for (int t = 0; t < cv.K; ++t)
+                    acc += s_w[col * cv.K + t] * grad_at(a.go, &gs, co, obase + (size_t)li * cv.stride + t, nullptr, nullptr);
+            } else {
+                // padded positions p that read input element li
+                int p0 = li + cv.pad, p1 = li + cv.pad;
+                if (cv.pad_replicate) {
+                    if (li == 0) p0 = 0;
+                    if (li == cv.Lin - 1) p1 = cv.Lin - 1 + 2 * cv.pad;
+                }
+                for (int p = p0; p <= p1; ++p)
+                    for (int t = 0; t < cv.K; ++t) {
+                        const int num = p - t;
+                        if (num < 0) break;
+                        if (num % cv.stride) continue;
+                        const int l = num / cv.stride;
+                        if (l >= cv.Lout) continue;
+                        acc += s_w[col * cv.K + t] * grad_at(a.go, &gs, co, obase + l, nullptr, nullptr);
+                    }
+            }
+        }
+        const size_t idx = ((size_t)b * cv.Cin + ci) * cv.Lin + li;
+        if (a.in.mask) acc *= a.in.mask[idx];
+        if (a.accumulate) acc += a.din[idx];
+        a.din[idx] = acc;
+        if (a.din_partials) {
+            const float y = view_y(a.in, &vs, ci, idx);
+            s_acc += (double)acc; q_acc += (double)acc * (double)y;
+        }
+    }
+    if (a.din_partials) {
+        const double s = raae::block_sum(s_acc, shd);
+        const double q = raae::block_sum(q_acc, shd);
+        if (threadIdx.x == 0) {
+            double* p = a.din_partials + ((size_t)sl * cv.Cin + ci) * 2;
+            p[0] = s; p[1] = q;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ conv backward (parameters)
+struct ConvBwdWArgs {
+    raae_grad_t go; int B; raae_conv_t cv; raae_view_t in; float* dw; float* dbias; float* dslope; int nw;
+};
+
+// workgroup e < nw: weight element e (torch layout); nw <= e < nw+Cout: dbias; then dslope.
+__global__ __launch_bounds__(256) void conv_bwd_weight_kernel(ConvBwdWArgs a) {
+    __shared__ ViewStats vs;
+    __shared__ GradStats gs;
+    __shared__ double shd[16];
+    const raae_conv_t& cv = a.cv;
+    const int cig = cv.Cin / cv.groups, cog = cv.Cout / cv.groups;
+    view_prologue(a.in, cv.Cin, &vs, false);
+    grad_prologue(a.go, cv.Cout, &gs);
+    const int e = blockIdx.x;
+    double acc = 0.0;
+    if (e < a.nw) {
+        int co, ci, t;
+        if (cv.transposed) {        // [Cin][cog][K]
+            t = e % cv.K; const int col = (e / cv.K) % cog; ci = e / (cv.K * cog);
+            co = (ci / cig) * cog + col;
+        } else {                    // [Cout][cig][K]
+            t = e % cv.K; const int cil = (e / cv.K) % cig; co = e / (cv.K * cig);
+            ci = (co / cog) * cig + cil;
+        }
+        const long total = (long)a.B * (cv.transposed ? cv.Lin : cv.Lout);
+        for (long i = threadIdx.x; i < total; i += 256) {
+            if (cv.transposed) {
+                const int b = (int)(i / cv.Lin), li = (int)(i - (long)b * cv.Lin);
+                const float x = view_at(a.in, &vs, ci, ((size_t)b * cv.Cin + ci) * cv.Lin + li);
+                const float g = grad_at(a.go, &gs, co, ((size_t)b * cv.Cout + co) * cv.Lout + (size_t)li * cv.stride + t,
+                                        nullptr, nullptr);
+                acc += (double)x * (double)g;
+            } else {
+                const int b = (int)(i / cv.Lout), l = (int)(i - (long)b * cv.Lout);
+                int p = l * cv.stride + t - cv.pad;
+                if (p < 0 || p >= cv.Lin) {
+                    if (!cv.pad_replicate) continue;
+                    p = p < 0 ? 0 : cv.Lin - 1;
+                }
+                const float x = view_at(a.in, &vs, ci, ((size_t)b * cv.Cin + ci) * cv.Lin + p);
+                const float g = grad_at(a.go, &gs, co, ((size_t)b * cv.Cout + co) * cv.Lout + l, nullptr, nullptr);
+                acc += (double)x * (double)g;
+            }
+        }
+        const double t2 = raae::block_sum(acc, shd);
+        if (threadIdx.x == 0) a.dw[e] = (float)t2;
+    } else {
+        const bool is_bias = e < a.nw + cv.Cout;
+        const int co = is_bias ? e - a.nw : e - a.nw - cv.Cout;
+        if (!is_bias && a.dslope == nullptr) return;
+        const long total = (long)a.B * cv.Lout;
+        for (long i = threadIdx.x; i < total; i += 256) {
+            const int b = (int)(i / cv.Lout), l = (int)(i - (long)b * cv.Lout);
+            float da, raw;
+            const float g = grad_at(a.go, &gs, co, ((size_t)b * cv.Cout + co) * cv.Lout + l, &da, &raw);
+            if (is_bias) acc += (double)g;
+            else if (raw <= 0.f) acc += (double)da * (double)raw;
+        }
+        const double t2 = raae::block_sum(acc, shd);
+        if (threadIdx.x == 0) { if (is_bias) a.dbias[co] = (float)t2; else a.dslope[co] = (float)t2; }
+    }
+}
+
+// ------------------------------------------------------------------ length-axis Linear
+struct LenLinFwdArgs {
+    raae_view_t in; int B; int C; int Lin; const float* w; const float* bias; int E; float* out;
+    int stats_kind; const float* out_slope; double* out_partials; int nsl;
+};
+
+__global__ __launch_bounds__(256) void lenlin_fwd_kernel(LenLinFwdArgs a) {
+    __shared__ ViewStats vs;
+    __shared__ double shd[16];
+    const int c = blockIdx.x % a.C, sl = blockIdx.x / a.C;
+    view_prologue(a.in, a.C, &vs, blockIdx.x == 0);
+    const float oslope = (a.stats_kind == RAAE_OUT_STATS_PRELU) ? a.out_slope[c] : 1.f;
+    long lo, hi;
+    slice_range((long)a.B * a.E, a.nsl, sl, &lo, &hi);
+    double s_acc = 0.0, q_acc = 0.0;
+    for (long i = lo + threadIdx.x; i < hi; i += 256) {
+        const int b = (int)(i / a.E), e = (int)(i - (long)b * a.E);
+        const size_t base = ((size_t)b * a.C + c) * a.Lin;
+        float acc = a.bias[e];
+        for (int l = 0; l < a.Lin; ++l) acc += a.w[(size_t)e * a.Lin + l] * view_at(a.in, &vs, c, base + l);
+        a.out[((size_t)b * a.C + c) * a.E + e] = acc;
+        if (a.stats_kind != RAAE_OUT_RAW) {
+            const float v = (a.stats_kind == RAAE_OUT_STATS_PRELU) ? prelu(acc, oslope) : acc;
+            s_acc += (double)v; q_acc += (double)v * (double)v;
+        }
+    }
+    if (a.stats_kind != RAAE_OUT_RAW) {
+        const double s = raae::block_sum(s_acc, shd);
+        const double q = raae::block_sum(q_acc, shd);
+        if (threadIdx.x == 0) {
+            double* p = a.out_partials + ((size_t)sl * a.C + c) * 2;
+            p[0] = s; p[1] = q;
+        }
+    }
+}
+
+struct LenLinBwdDataArgs {
+    raae_grad_t go; int B; int C; int E; const float* w; raae_view_t in; int Lin; float* din; int accumulate;
+    double* din_partials; int nsl;
+};
+
+__global__ __launch_bounds__(256) void lenlin_bwd_data_kernel(LenLinBwdDataArgs a) {
+    __shared__ ViewStats vs;
+    __shared__ GradStats gs;
+    __shared__ double shd[16];
+    const int c = blockIdx.x % a.C, sl = blockIdx.x / a.C;
+    view_prologue(a.in, a.C, &vs, false);
+    grad_prologue(a.go, a.C, &gs);
+    long lo, hi;
+    slice_range((long)a.B * a.Lin, a.nsl, sl, &lo, &hi);
+    double s_acc = 0.0, q_acc = 0.0;
+    for (long i = lo + threadIdx.x; i < hi; i += 256) {
+        const int b = (int)(i / a.Lin), l = (int)(i - (long)b * a.Lin);
+        const size_t obase = ((size_t)b * a.C + c) * a.E;
+        float acc = 0.f;
+        for (int e = 0; e < a.E; ++e)
+            acc += a.w[(size_t)e * a.Lin + l] * grad_at(a.go, &gs, c, obase + e, nullptr, nullptr);
+        const size_t idx = ((size_t)b * a.C + c) * a.Lin + l;
+        if (a.in.mask) acc *= a.in.mask[idx];
+        if (a.accumulate) acc += a.din[idx];
+        a.din[idx] = acc;
+        if (a.din_partials) {
+            const float y = view_y(a.in, &vs, c, idx);
+            s_acc += (double)acc; q_acc += (double)acc * (double)y;
+        }
+    }
+    if (a.din_partials) {
+        const double s = raae::block_sum(s_acc, shd);
+        const double q = raae::block_sum(q_acc, shd);
+        if (threadIdx.x == 0) {
+            double* p = a.din_partials + ((size_t)sl * a.C + c) * 2;
+            p[0] = s; p[1] = q;
+        }
+    }
+}
+
+struct LenLinBwdWArgs {
+    raae_grad_t go; int B; int C; int E; raae_view_t in; int Lin; float* dw; float* dbias; float* dslope;
+};
+
+// workgroup x < E*Lin: dW[e][l]; then E workgroups dbias[e]; then C workgroups dslope[c]
+__global__ __launch_bounds__(256) void lenlin_bwd_weight_kernel(LenLinBwdWArgs a) {
+    __shared__ ViewStats vs;
+    __shared__ GradStats gs;
+    __shared__ double shd[16];
+    view_prologue(a.in, a.C, &vs, false);
+    grad_prologue(a.go, a.C, &gs);
+    const int x = blockIdx.x, nw = a.E * a.Lin;
+    double acc = 0.0;
+    if (x < nw) {
+        const int e = x / a.Lin, l = x - e * a.Lin;
+        const long total = (long)a.B * a.C;
+        for (long i = threadIdx.x; i < total; i += 256) {
+            const int c = (int)(i % a.C);
+            const float g = grad_at(a.go, &gs, c, (size_t)i * a.E + e, nullptr, nullptr);
+            acc += (double)g * (double)view_at(a.in, &vs, c, (size_t)i * a.Lin + l);
+        }
+        const double t = raae::block_sum(acc, shd);
+        if (threadIdx.x == 0) a.dw[x] = (float)t;
+    } else if (x < nw + a.E) {
+        const int e = x - nw;
+        const long total = (long)a.B * a.C;
+        for (long i = threadIdx.x; i < total; i += 256)
+            acc += (double)grad_at(a.go, &gs, (int)(i % a.C), (size_t)i * a.E + e, nullptr, nullptr);
+        const double t = raae::block_sum(acc, shd);
+        if (threadIdx.x == 0) a.dbias[e] = (float)t;
+    } else {
+        if (a.dslope == nullptr) return;
+        const int c = x - nw - a.E;
+        const long total = (long)a.B * a.E;
+        for (long i = threadIdx.x; i < total; i += 256) {
+            const int b = (int)(i / a.E), e = (int)(i - (long)b * a.E);
+            float da, raw;
+            grad_at(a.go, &gs, c, ((size_t)b * a.C + c) * a.E + e, &da, &raw);
+            if (raw <= 0.f) acc += (double)da * (double)raw;
+        }
+        const double t = raae::block_sum(acc, shd);
+        if (threadIdx.x == 0) a.dslope[c] = (float)t;
+    }
+}
+
+// ------------------------------------------------------------------ block sum / grad materialise
+struct Sum3Args { raae_view_t a, b, c; int B; int C; int L; float* y; double* out_partials; int nsl; };
+
+__global__ __launch_bounds__(256) void sum3_kernel(Sum3Args a) {
+    __shared__ ViewStats va, vb, vc;
+    __shared__ double shd[16];
+    const int c = blockIdx.x % a.C, sl = blockIdx.x / a.C;
+    view_prologue(a.a, a.C, &va, false);
+    view_prologue(a.b, a.C, &vb, blockIdx.x == 0);
+    view_prologue(a.c, a.C, &vc, false);
+    long lo, hi;
+    slice_range((long)a.B * a.L, a.nsl, sl, &lo, &hi);
+    double s_acc = 0.0, q_acc = 0.0;
+    for (long i = lo + threadIdx.x; i < hi; i += 256) {
+        const int b = (int)(i / a.L), l = (int)(i - (long)b * a.L);
+        const size_t idx = ((size_t)b * a.C + c) * a.L + l;
+        const float v = view_at(a.a, &va, c, idx) + view_at(a.b, &vb, c, idx) + view_at(a.c, &vc, c, idx);
+        a.y[idx] = v;
+        s_acc += (double)v; q_acc += (double)v * (double)v;
+    }
+    if (a.out_partials) {
+        const double s = raae::block_sum(s_acc, shd);
+        const double q = raae::block_sum(q_acc, shd);
+        if (threadIdx.x == 0) {
+            double* p = a.out_partials + ((size_t)sl * a.C + c) * 2;
+            p[0] = s; p[1] = q;
+        }
+    }
+}
+
+struct GradMatArgs { raae_grad_t go; int B; int C; int L; float* draw; float* dslope; int accumulate; };
+
+// one workgroup per channel: writes dRaw (if draw) and the final dslope[c] (if dslope)
+__global__ __launch_bounds__(256) void grad_materialize_kernel(GradMatArgs a) {
+    __shared__ GradStats gs;
+    __shared__ double shd[16];
+    const int c = blockIdx.x;
+    grad_prologue(a.go, a.C, &gs);
+    double acc = 0.0;
+    const long total = (long)a.B * a.L;
+    for (long i = threadIdx.x; i < total; i += 256) {
+        const int b = (int)(i / a.L), l = (int)(i - (long)b * a.L);
+        const size_t idx = ((size_t)b * a.C + c) * a.L + l;
+        float da, raw;
+        const float dr = grad_at(a.go, &gs, c, idx, &da, &raw);
+        if (a.draw) a.draw[idx] = a.accumulate ? a.draw[idx] + dr : dr;
+        if (raw <= 0.f) acc += (double)da * (double)raw;
+    }
+    if (a.dslope) {
+        const double t = raae::block_sum(acc, shd);
+        if (threadIdx.x == 0) a.dslope[c] = (float)t;
+    }
+}
+
+int slices_for(long per_channel, int C) {
+    long n = (per_channel + 255) / 256;
+    long cap = RAAE_MAX_PARTS;
+    if (n > cap) n = cap;
+    if (n < 1) n = 1;
+    (void)C;
+    return (int)n;
+}
+
+bool view_ok(const raae_view_t* v, int C) {
+    return v && v->raw && C <= CV_MAXC && (!v->has_bn || (v->bn.nparts <= RAAE_MAX_PARTS &&
+                                                         (v->bn.partials || (v->bn.running_mean && v->bn.running_var))));
+}
+bool grad_ok(const raae_grad_t* g, int C) {
+    return g && g->g && C <= CV_MAXC && (g->raw || (!g->slope && g->act == RAAE_OUT_RAW && (!g->has_bn || g->u)))
+           && (!g->has_bn || (g->g_partials && g->g_nparts > 0 && g->g_nparts <= RAAE_MAX_PARTS && g->bn.partials));
+}
+bool conv_ok(const raae_conv_t* cv) {
+    if (!cv || cv->Cin < 1 || cv->Cout < 1 || cv->K < 1 || cv->K > 16 || cv->stride < 1 || cv->groups < 1) return false;
+    if (cv->Cin % cv->groups || cv->Cout % cv->groups || cv->Cin > CV_MAXC || cv->Cout > CV_MAXC) return false;
+    if (cv->transposed) return cv->K == cv->stride && cv->pad == 0 && cv->Lout == cv->Lin * cv->stride;
+    return cv->Lout == (cv->Lin + 2 * cv->pad - cv->K) / cv->stride + 1;
+}
+
+}  // namespace
+
+extern "C" int raae_conv_fwd(const raae_view_t* in, int B, const raae_conv_t* cv, const float* w, const float* bias,
+                             float* out, int stats_kind, const float* out_slope, double* out_partials, int* out_nparts,
+                             int act, void* stream) {
+    RAAE_CHECK_ARG(conv_ok(cv) && view_ok(in, cv->Cin) && w && bias && out && B > 0);
+    RAAE_CHECK_ARG(stats_kind == RAAE_OUT_RAW || out_partials);
+    RAAE_CHECK_ARG(stats_kind != RAAE_OUT_STATS_PRELU || out_slope);
+    ConvFwdArgs a;
+    a.in = *in; a.B = B; a.cv = *cv; a.w = w; a.bias = bias; a.out = out; a.stats_kind = stats_kind;
+    a.out_slope = out_slope; a.out_partials = out_partials; a.act = act;
+    a.nsl = slices_for((long)B * cv->Lout, cv->Cout);
+    if (out_nparts) *out_nparts = a.nsl;
+    hipLaunchKernelGGL(conv_fwd_kernel, dim3(a.nsl * cv->Cout), dim3(256), 0, (hipStream_t)stream, a);
+    RAAE_LAUNCH_RET();
+}
+
+extern "C" int raae_conv_bwd_data(const raae_grad_t* go, int B, const raae_conv_t* cv, const float* w,
+                                  const raae_view_t* in, float* din, int accumulate, double* din_partials,
+                                  int* din_nparts, void* stream) {
+    RAAE_CHECK_ARG(conv_ok(cv) && grad_ok(go, cv->Cout) && view_ok(in, cv->Cin) && w && din && B > 0);
+    RAAE_CHECK_ARG(!din_partials || in->has_bn);
+    ConvBwdDataArgs a;
+    a.go = *go; a.B = B; a.cv = *cv; a.w = w; a.in = *in; a.din = din; a.accumulate = accumulate;
+    a.din_partials = din_partials;
+    a.nsl = slices_for((long)B * cv->Lin, cv->Cin);
+    if (din_nparts) *din_nparts = a.nsl;
+    hipLaunchKernelGGL(conv_bwd_data_kernel, dim3(a.nsl * cv->Cin), dim3(256), 0, (hipStream_t)stream, a);
+    RAAE_LAUNCH_RET();
+}
+
+extern "C" int raae_conv_bwd_weight(const raae_grad_t* go, int B, const raae_conv_t* cv, const raae_view_t* in,
+                                    float* dw, float* dbias, float* dslope, void* stream) {
+    RAAE_CHECK_ARG(conv_ok(cv) && grad_ok(go, cv->Cout) && view_ok(in, cv->Cin) && dw && dbias && B > 0);
+    RAAE_CHECK_ARG(!dslope || go->slope);
+    ConvBwdWArgs a;
+    a.go = *go; a.B = B; a.cv = *cv; a.in = *in; a.dw = dw; a.dbias = dbias; a.dslope = dslope;
+    a.nw = cv->transposed ? cv->Cin * (cv->Cout / cv->groups) * cv->K : cv->Cout * (cv->Cin / cv->groups) * cv->K;
+    hipLaunchKernelGGL(conv_bwd_weight_kernel, dim3(a.nw + 2 * cv->Cout), dim3(256), 0, (hipStream_t)stream, a);
+    RAAE_LAUNCH_RET();
+}
+
+extern "C" int raae_lenlin_fwd(const raae_view_t* in, int B, int C, int Lin, const float* w, const float* bias, int E,
+                               float* out, int stats_kind, const float* out_slope, double* out_partials,
+                               int* out_nparts, void* stream) {
+    RAAE_CHECK_ARG(view_ok(in, C) && w && bias && out && B > 0 && C > 0 && Lin > 0 && E > 0);
+    RAAE_CHECK_ARG(stats_kind == RAAE_OUT_RAW || out_partials);
+    RAAE_CHECK_ARG(stats_kind != RAAE_OUT_STATS_PRELU || out_slope);
+    LenLinFwdArgs a;
+    a.in = *in; a.B = B; a.C = C; a.Lin = Lin; a.w = w; a.bias = bias; a.E = E; a.out = out;
+    a.stats_kind = stats_kind; a.out_slope = out_slope; a.out_partials = out_partials;
+    a.nsl = slices_for((long)B * E, C);
+    if (out_nparts) *out_nparts = a.nsl;
+    hipLaunchKernelGGL(lenlin_fwd_kernel, dim3(a.nsl * C), dim3(256), 0, (hipStream_t)stream, a);
+    RAAE_LAUNCH_RET();
+}
+
+extern "C" int raae_lenlin_bwd_data(const raae_grad_t* go, int B, int C, int E, const float* w, const raae_view_t* in,
+                                    int Lin, float* din, int accumulate, double* din_partials, int* din_nparts,
+                                    void* stream) {
+    RAAE_CHECK_ARG(grad_ok(go, C) && view_ok(in, C) && w && din && B > 0 && E > 0 && Lin > 0);
+    RAAE_CHECK_ARG(!din_partials || in->has_bn);
+    LenLinBwdDataArgs a;
+    a.go = *go; a.B = B; a.C = C; a.E = E; a.w = w; a.in = *in; a.Lin = Lin; a.din = din; a.accumulate = accumulate;
+    a.din_partials = din_partials;
+    a.nsl = slices_for((long)B * Lin, C);
+    if (din_nparts) *din_nparts = a.nsl;
+    hipLaunchKernelGGL(lenlin_bwd_data_kernel, dim3(a.nsl * C), dim3(256), 0, (hipStream_t)stream, a);
+    RAAE_LAUNCH_RET();
+}
+
+extern "C" int raae_lenlin_bwd_weight(const raae_grad_t* go, int B, int C, int E, const raae_view_t* in, int Lin,
+                                      float* dw, float* dbias, float* dslope, void* stream) {
+    RAAE_CHECK_ARG(grad_ok(go, C) && view_ok(in, C) && dw && dbias && B > 0 && E > 0 && Lin > 0);
+    RAAE_CHECK_ARG(!dslope || go->slope);
+    LenLinBwdWArgs a;
+    a.go = *go; a.B = B; a.C = C; a.E = E; a.in = *in; a.Lin = Lin; a.dw = dw; a.dbias = dbias; a.dslope = dslope;
+    hipLaunchKernelGGL(lenlin_bwd_weight_kernel, dim3(E * Lin + E + C), dim3(256), 0, (hipStream_t)stream, a);
+    RAAE_LAUNCH_RET();
+}
+
+extern "C" int raae_sum3_fwd(const raae_view_t* a_, const raae_view_t* b_, const raae_view_t* c_, int B, int C, int L,
+                             float* y, double* out_partials, int* out_nparts, void* stream) {
+    RAAE_CHECK_ARG(view_ok(a_, C) && view_ok(b_, C) && view_ok(c_, C) && y && B > 0 && L > 0);
+    Sum3Args a;
+    a.a = *a_; a.b = *b_; a.c = *c_; a.B = B; a.C = C; a.L = L; a.y = y; a.out_partials = out_partials;
+    a.nsl = slices_for((long)B * L, C);
+    if (out_nparts) *out_nparts = a.nsl;
+    hipLaunchKernelGGL(sum3_kernel, dim3(a.nsl * C), dim3(256), 0, (hipStream_t)stream, a);
+    RAAE_LAUNCH_RET();
+}
+
+extern "C" int raae_grad_materialize(const raae_grad_t* go, int B, int C, int L, float* draw, int accumulate,
+                                     float* dslope, void* stream) {
+    RAAE_CHECK_ARG(grad_ok(go, C) && (draw || dslope) && B > 0 && L > 0 && C > 0);
+    RAAE_CHECK_ARG(!dslope || go->slope);
+    GradMatArgs a;
+    a.go = *go; a.B = B; a.C = C; a.L = L; a.draw = draw; a.dslope = dslope; a.accumulate = accumulate;
+    hipLaunchKernelGGL(grad_materialize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, a);
+    RAAE_LAUNCH_RET();
+}

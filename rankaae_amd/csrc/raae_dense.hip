@@ -19,71 +19,103 @@ using raae::prelu;
 struct DenseFwdArgs {
     const float* x; int B; int K; int in_kind; const float* slope; raae_bn_t bn; const float* mask;
     const float* w; const float* bias; int N; float* z; int out_kind; const float* out_slope;
-    double* out_partials; int KC; int pitch; int resident;
+    double* out_partials; int pitch;
 };
 
-// dynamic LDS: s_mean[K4] s_rstd[K4] s_slope[K4] | Ws[64][pitch] | Xs[16][pitch]
+// Input transform of one element (PReLU -> BatchNorm -> Dropout scale), statistics from LDS.
+__device__ __forceinline__ float in_transform(float v, int k, int in_kind, const float* s_slope, const float* s_mean,
+                                              const float* s_rstd) {
+    if (in_kind != RAAE_IN_NONE) {
+        v = prelu(v, s_slope[k]);
+        if (in_kind == RAAE_IN_PRELU_BN_DROP) v = (v - s_mean[k]) * s_rstd[k];
+    }
+    return v;
+}
+
+// Stage a 16-row tile of the layer input into LDS (transform applied, zero padded to K4 columns).
+// Vector path (K % 4 == 0): one float4 per thread per pass, no integer division in the loop.
+__device__ __forceinline__ void stage_rows(float* Xs, int pitch, const float* x, const float* mask, int row0, int B,
+                                           int K, int K4, int in_kind, const float* s_slope, const float* s_mean,
+                                           const float* s_rstd) {
+    const int tid = threadIdx.x;
+    if ((K & 3) == 0) {
+        const int kq = K >> 2;                       // float4s per row
+        int r = tid / kq, c4 = tid - r * kq;
+        const int dr = 256 / kq, dc = 256 - dr * kq;
+        for (; r < 16; ) {
+            const int row = row0 + r, k = c4 << 2;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < B) {
+                v = *reinterpret_cast<const float4*>(x + (size_t)row * K + k);
+                v.x = in_transform(v.x, k, in_kind, s_slope, s_mean, s_rstd);
+                v.y = in_transform(v.y, k + 1, in_kind, s_slope, s_mean, s_rstd);
+                v.z = in_transform(v.z, k + 2, in_kind, s_slope, s_mean, s_rstd);
+                v.w = in_transform(v.w, k + 3, in_kind, s_slope, s_mean, s_rstd);
+                if (in_kind != RAAE_IN_NONE && mask) {
+                    const float4 m = *reinterpret_cast<const float4*>(mask + (size_t)row * K + k);
+                    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+                }
+            }
+            float2* dst = reinterpret_cast<float2*>(Xs + r * pitch + k);     // pitch even => 8-B aligned
+            dst[0] = make_float2(v.x, v.y);
+            dst[1] = make_float2(v.z, v.w);
+            r += dr; c4 += dc;
+            if (c4 >= kq) { c4 -= kq; ++r; }
+        }
+    } else {
+        for (int idx = tid; idx < 16 * K4; idx += 256) {
+            const int r = idx / K4, k = idx - r * K4;
+            const int row = row0 + r;
+            float v = 0.f;
+            if (row < B && k < K) {
+                v = in_transform(x[(size_t)row * K + k], k, in_kind, s_slope, s_mean, s_rstd);
+                if (in_kind != RAAE_IN_NONE && mask) v *= mask[(size_t)row * K + k];
+            }
+            Xs[r * pitch + k] = v;
+        }
+    }
+}
+
+// dynamic LDS: s_mean[K4] s_rstd[K4] s_slope[K4] | Xs[16][pitch].  The wave's 16 output columns of W
+// stay in registers (KQ floats per lane = the B operands of all K/4 MFMA steps) across its row tiles.
+template <int KQ>
 __global__ __launch_bounds__(256) void dense_fwd_kernel(DenseFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int K4 = (a.K + 3) & ~3;
     float* s_mean = smem;
     float* s_rstd = s_mean + K4;
     float* s_slope = s_rstd + K4;
-    float* Ws = s_slope + K4;
-    float* Xs = Ws + 64 * a.pitch;
+    float* Xs = s_slope + K4;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int n0 = blockIdx.y * 64;
+    const int col = blockIdx.y * 64 + wv * 16 + (lane & 15);
 
-    if (a.in_kind == RAAE_IN_PRELU_BN_DROP) {
+    float wreg[KQ];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+        const int k = 4 * q + (lane >> 4);
+        wreg[q] = (col < a.N && k < a.K) ? a.w[(size_t)col * a.K + k] : 0.f;
+    }
+    if (a.in_kind == RAAE_IN_PRELU_BN_DROP)
         raae::bn_prologue(a.bn, a.K, s_mean, s_rstd, blockIdx.x == 0 && blockIdx.y == 0);
-    }
-    if (a.in_kind != RAAE_IN_NONE) {
+    if (a.in_kind != RAAE_IN_NONE)
         for (int k = tid; k < a.K; k += 256) s_slope[k] = a.slope[k];
-    }
     __syncthreads();
 
     const int ntiles = (a.B + 15) >> 4;
-    const int col = n0 + wv * 16 + (lane & 15);
     const float bias = (col < a.N) ? a.bias[col] : 0.f;
     const float oslope = (a.out_kind == RAAE_OUT_STATS_PRELU && col < a.N) ? a.out_slope[col] : 1.f;
     double s_acc = 0.0, q_acc = 0.0;
-    bool w_staged = false;
+    const float* xa = Xs + (lane & 15) * a.pitch + (lane >> 4);
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile << 4;
+        stage_rows(Xs, a.pitch, a.x, a.mask, row0, a.B, a.K, K4, a.in_kind, s_slope, s_mean, s_rstd);
+        __syncthreads();
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int kc0 = 0; kc0 < K4; kc0 += a.KC) {
-            const int kcur = min(a.KC, K4 - kc0);
-            if (!(a.resident && w_staged)) {
-                for (int idx = tid; idx < 64 * kcur; idx += 256) {
-                    const int c = idx / kcur, kk = idx - c * kcur;
-                    const int n = n0 + c, k = kc0 + kk;
-                    Ws[c * a.pitch + kk] = (n < a.N && k < a.K) ? a.w[(size_t)n * a.K + k] : 0.f;
-                }
-                w_staged = true;
-            }
-            for (int idx = tid; idx < 16 * kcur; idx += 256) {
-                const int r = idx / kcur, kk = idx - r * kcur;
-                const int row = row0 + r, k = kc0 + kk;
-                float v = 0.f;
-                if (row < a.B && k < a.K) {
-                    v = a.x[(size_t)row * a.K + k];
-                    if (a.in_kind != RAAE_IN_NONE) {
-                        v = prelu(v, s_slope[k]);
-                        if (a.in_kind == RAAE_IN_PRELU_BN_DROP) v = (v - s_mean[k]) * s_rstd[k];
-                        if (a.mask) v *= a.mask[(size_t)row * a.K + k];
-                    }
-                }
-                Xs[r * a.pitch + kk] = v;
-            }
-            __syncthreads();
-            const float* xa = Xs + (lane & 15) * a.pitch + (lane >> 4);
-            const float* wb = Ws + (wv * 16 + (lane & 15)) * a.pitch + (lane >> 4);
-            for (int kk = 0; kk < kcur; kk += 4) {
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kk], wb[kk], acc, 0, 0, 0);
-            }
-            __syncthreads();
-        }
+#pragma unroll
+        for (int q = 0; q < KQ; ++q)
+            if (4 * q < K4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[4 * q], wreg[q], acc, 0, 0, 0);
+        __syncthreads();
         // epilogue: lane holds rows row0 + (lane>>4)*4 + j of column `col`
         if (col < a.N) {
 #pragma unroll
@@ -200,21 +232,8 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
                 Gs[r * a.pitch_g + n] = dz;
             }
         }
-        // ---- 2. layer input tile -> Xs (transform applied, zero padded) ----
-        for (int idx = tid; idx < 16 * K16; idx += 256) {
-            const int r = idx / K16, k = idx - r * K16;
-            const int row = row0 + r;
-            float v = 0.f;
-            if (row < a.B && k < a.K) {
-                v = a.x[(size_t)row * a.K + k];
-                if (a.in_kind != RAAE_IN_NONE) {
-                    v = prelu(v, i_slope[k]);
-                    if (a.in_kind == RAAE_IN_PRELU_BN_DROP) v = (v - i_mean[k]) * i_rstd[k];
-                    if (a.mask) v *= a.mask[(size_t)row * a.K + k];
-                }
-            }
-            Xs[r * a.pitch_x + k] = v;
-        }
+        // ---- 2. layer input tile -> Xs (transform applied) ----
+        stage_rows(Xs, a.pitch_x, a.x, a.mask, row0, a.B, a.K, K16, a.in_kind, i_slope, i_mean, i_rstd);
         __syncthreads();
         // ---- 3. dW[n][k] += sum_rows dz[row][n] * xin[row][k]; wave owns tiles t = wv + 4 i ----
 #pragma unroll
@@ -239,10 +258,30 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
                     const int kcol = tk * 16 + (lane & 15);
                     const float* ga = Gs + (lane & 15) * a.pitch_g + (lane >> 4);
                     const bool kok = kcol < a.K;
-                    for (int nn = 0; nn < N16; nn += 4) {
-                        const int n = nn + (lane >> 4);
-                        const float b = (kok && n < a.N) ? a.w[(size_t)n * a.K + kcol] : 0.f;
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[nn], b, acc, 0, 0, 0);
+                    // B operand W[n][kcol]: 16 independent loads in flight per group of 16 MFMA steps
+                    const float* wp = a.w + (size_t)(lane >> 4) * a.K + kcol;
+                    int nn = 0;
+                    for (; nn + 64 <= N16; nn += 64) {
+                        float bb[16];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) {
+                            const int n = nn + 4 * u + (lane >> 4);
+                            bb[u] = (kok && n < a.N) ? wp[(size_t)(nn + 4 * u) * a.K] : 0.f;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 16; ++u)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[nn + 4 * u], bb[u], acc, 0, 0, 0);
+                    }
+                    for (; nn < N16; nn += 16) {
+                        float bb[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int n = nn + 4 * u + (lane >> 4);
+                            bb[u] = (kok && n < a.N) ? wp[(size_t)(nn + 4 * u) * a.K] : 0.f;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[nn + 4 * u], bb[u], acc, 0, 0, 0);
                     }
                     if (kok) {
 #pragma unroll
@@ -328,7 +367,7 @@ int pick_grid(int B) {
 extern "C" int raae_dense_fwd(const float* x, int B, int K, int in_kind, const float* slope, const raae_bn_t* bn,
                               const float* mask, const float* w, const float* bias, int N, float* z, int out_kind,
                               const float* out_slope, double* out_partials, int* out_nparts, void* stream) {
-    RAAE_CHECK_ARG(x && w && bias && z && B > 0 && K > 0 && N > 0 && K <= 4096);
+    RAAE_CHECK_ARG(x && w && bias && z && B > 0 && K > 0 && N > 0 && K <= 512);
     RAAE_CHECK_ARG(in_kind >= 0 && in_kind <= 2 && out_kind >= 0 && out_kind <= 4);
     RAAE_CHECK_ARG(in_kind == RAAE_IN_NONE || slope);
     RAAE_CHECK_ARG(in_kind != RAAE_IN_PRELU_BN_DROP || (bn && (bn->partials || (bn->running_mean && bn->running_var))));
@@ -341,14 +380,16 @@ extern "C" int raae_dense_fwd(const float* x, int B, int K, int in_kind, const f
     a.w = w; a.bias = bias; a.N = N; a.z = z; a.out_kind = out_kind; a.out_slope = out_slope;
     a.out_partials = out_partials;
     const int K4 = (K + 3) & ~3;
-    a.KC = K4 < 256 ? K4 : 256;
-    a.pitch = a.KC + 2;
-    a.resident = (K4 <= 256) ? 1 : 0;
-    const size_t lds = sizeof(float) * (3 * (size_t)K4 + 80 * (size_t)a.pitch);
-    RAAE_CHECK_ARG(lds <= 160 * 1024);
+    RAAE_CHECK_ARG(K4 <= 512 && (in_kind != RAAE_IN_PRELU_BN_DROP || K <= 256));
+    a.pitch = K4 + 2;
+    const size_t lds = sizeof(float) * (3 * (size_t)K4 + 16 * (size_t)a.pitch);
     dim3 grid(pick_grid(B), (N + 63) / 64);
     if (out_nparts) *out_nparts = (int)grid.x;
-    hipLaunchKernelGGL(dense_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+    if (K4 <= 16) hipLaunchKernelGGL(dense_fwd_kernel<4>, grid, dim3(256), lds, st, a);
+    else if (K4 <= 64) hipLaunchKernelGGL(dense_fwd_kernel<16>, grid, dim3(256), lds, st, a);
+    else if (K4 <= 256) hipLaunchKernelGGL(dense_fwd_kernel<64>, grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(dense_fwd_kernel<128>, grid, dim3(256), lds, st, a);
     RAAE_LAUNCH_RET();
 }
 

@@ -66,70 +66,119 @@ struct RankWork {   // per-workgroup partial: [k]{n_pos, n_neg} ints and {S_pos,
     double s_pos[RANK_MAXK], s_neg[RANK_MAXK];
 };
 
-template <int KA>
+#define RANK_JC 8      // lanes that share one (row, descriptor) and split the j range
+// Thread = (row i, descriptor k, j-chunk c); R rows per thread (register blocking for large B).
+// The 8 chunk lanes of a (row, k) are adjacent lanes: their partial results meet through
+// wavefront shuffles (xor 1, 2, 4).  Workgroups grid-stride over row groups.
+template <int KA, int R>
 __global__ __launch_bounds__(256) void rank_pairs_kernel(const float* d, int ldd, const float* z, int ldz, int B,
                                                          RankWork* part, float* gpos, float* gneg) {
+    constexpr int IPB = 32 / KA;            // (row, k) slots per block = IPB * KA <= 32
     __shared__ float sd[RANK_TJ * KA], sz[RANK_TJ * KA];
-    __shared__ double shd[16];
-    const int tid = threadIdx.x;
-    const int i = blockIdx.x * 256 + tid;
-    float di[KA], zi[KA], gp[KA], gn[KA], sp[KA], sn[KA];
-    int np[KA], nn[KA];
+    __shared__ double red_s[2][32];
+    __shared__ long long red_n[2][32];
+    const int tid = threadIdx.x, c = tid & (RANK_JC - 1), q = tid >> 3;
+    const int il = q / KA, k = q - il * KA;
+    const bool slot = il < IPB;
+    double tsp = 0.0, tsn = 0.0;            // block totals of this (il, k) slot over all its row groups
+    long long tnp = 0, tnn = 0;
+    const int rows_per_group = IPB * R;
+    const int ngroups = (B + rows_per_group - 1) / rows_per_group;
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        float di[R], zi[R], gp[R], gn[R], sp[R], sn[R];
+        int np[R], nn[R], irow[R];
 #pragma unroll
-    for (int k = 0; k < KA; ++k) {
-        di[k] = (i < B) ? d[(size_t)i * ldd + k] : 0.f;
-        zi[k] = (i < B) ? z[(size_t)i * ldz + k] : 0.f;
-        gp[k] = gn[k] = sp[k] = sn[k] = 0.f; np[k] = nn[k] = 0;
-    }
-    for (int j0 = 0; j0 < B; j0 += RANK_TJ) {
-        const int nj = min(RANK_TJ, B - j0);
-        __syncthreads();
-        for (int idx = tid; idx < nj * KA; idx += 256) {
-            const int jj = idx / KA, k = idx - jj * KA;
-            sd[idx] = d[(size_t)(j0 + jj) * ldd + k];
-            sz[idx] = z[(size_t)(j0 + jj) * ldz + k];
+        for (int r = 0; r < R; ++r) {
+            irow[r] = grp * rows_per_group + r * IPB + il;
+            const bool ok = slot && irow[r] < B;
+            di[r] = ok ? d[(size_t)irow[r] * ldd + k] : 0.f;
+            zi[r] = ok ? z[(size_t)irow[r] * ldz + k] : 0.f;
+            gp[r] = gn[r] = sp[r] = sn[r] = 0.f; np[r] = nn[r] = 0;
         }
-        __syncthreads();
-        if (i < B) {
-            for (int jj = 0; jj < nj; ++jj) {
+        for (int j0 = 0; j0 < B; j0 += RANK_TJ) {
+            const int nj = min(RANK_TJ, B - j0);
+            __syncthreads();
+            for (int idx = tid; idx < nj * KA; idx += 256) {
+                const int jj = idx / KA, kk = idx - jj * KA;
+                sd[idx] = d[(size_t)(j0 + jj) * ldd + kk];
+                sz[idx] = z[(size_t)(j0 + jj) * ldz + kk];
+            }
+            __syncthreads();
+            if (slot) {
+                for (int jj = c; jj < nj; jj += RANK_JC) {
+                    const float dj = sd[jj * KA + k], zj = sz[jj * KA + k];
 #pragma unroll
-                for (int k = 0; k < KA; ++k) {
-                    const float dd = di[k] - sd[jj * KA + k];
-                    const float s = dd > 0.f ? 1.f : (dd < 0.f ? -1.f : 0.f);
-                    const float p = (zi[k] - sz[jj * KA + k]) * s;
-                    if (p > 0.f) { np[k]++; sp[k] += p; gp[k] += s; }
-                    else if (p < 0.f) { nn[k]++; sn[k] += p; gn[k] += s; }
+                    for (int r = 0; r < R; ++r) {
+                        const float dd = di[r] - dj;
+                        const float sg = dd > 0.f ? 1.f : (dd < 0.f ? -1.f : 0.f);
+                        const float p = (zi[r] - zj) * sg;
+                        if (p > 0.f) { np[r]++; sp[r] += p; gp[r] += sg; }
+                        else if (p < 0.f) { nn[r]++; sn[r] += p; gn[r] += sg; }
+                    }
                 }
             }
         }
-    }
 #pragma unroll
-    for (int k = 0; k < KA; ++k) {
-        if (i < B) { gpos[(size_t)i * KA + k] = gp[k]; gneg[(size_t)i * KA + k] = gn[k]; }
-        const double a = raae::block_sum((double)sp[k], shd);
-        const double b = raae::block_sum((double)sn[k], shd);
-        const double c = raae::block_sum((double)np[k], shd);
-        const double e = raae::block_sum((double)nn[k], shd);
-        if (tid == 0) {
-            part[blockIdx.x].s_pos[k] = a; part[blockIdx.x].s_neg[k] = b;
-            part[blockIdx.x].n_pos[k] = (long long)(c + 0.5); part[blockIdx.x].n_neg[k] = (long long)(e + 0.5);
+        for (int r = 0; r < R; ++r) {
+            // rows beyond B hold di = zi = 0 against real j rows: discard them
+            const bool ok = slot && irow[r] < B;
+            float a = gp[r], b2 = gn[r];
+            double e = (double)sp[r], f = (double)sn[r];
+            int g = np[r], h = nn[r];
+#pragma unroll
+            for (int o = 1; o < RANK_JC; o <<= 1) {
+                a += __shfl_xor(a, o, 64); b2 += __shfl_xor(b2, o, 64);
+                e += __shfl_xor(e, o, 64); f += __shfl_xor(f, o, 64);
+                g += __shfl_xor(g, o, 64); h += __shfl_xor(h, o, 64);
+            }
+            if (ok && c == 0) {
+                gpos[(size_t)irow[r] * KA + k] = a; gneg[(size_t)irow[r] * KA + k] = b2;
+                tsp += e; tsn += f; tnp += g; tnn += h;
+            }
         }
+    }
+    // block totals per k: slots (il, k) combine in fixed order
+    __syncthreads();
+    if (c == 0) { red_s[0][q] = tsp; red_s[1][q] = tsn; red_n[0][q] = tnp; red_n[1][q] = tnn; }
+    __syncthreads();
+    if (tid < KA) {
+        double a = 0.0, b2 = 0.0; long long g = 0, h = 0;
+        for (int i2 = 0; i2 < IPB; ++i2) {
+            a += red_s[0][i2 * KA + tid]; b2 += red_s[1][i2 * KA + tid];
+            g += red_n[0][i2 * KA + tid]; h += red_n[1][i2 * KA + tid];
+        }
+        part[blockIdx.x].s_pos[tid] = a; part[blockIdx.x].s_neg[tid] = b2;
+        part[blockIdx.x].n_pos[tid] = g; part[blockIdx.x].n_neg[tid] = h;
     }
 }
 
-// finalize: c_k, loss, dz[i][k] = -(2/norm)(c_k g+ + g-).  grid-stride; every workgroup re-derives c_k.
+// finalize: c_k, loss, dz[i][k] = -(2/norm)(c_k g+ + g-).  Every workgroup re-derives c_k from the
+// partials (16 slices per descriptor, fixed order), then grid-strides over dz.
 __global__ __launch_bounds__(256) void rank_finalize_kernel(const RankWork* part, int nparts, int B, int KA, int activate,
                                                             const float* gpos, const float* gneg, float* loss,
                                                             float* dz, int ldz) {
     __shared__ float s_c[RANK_MAXK];
     __shared__ double s_loss[RANK_MAXK];
+    __shared__ double r_s[2][256];
+    __shared__ long long r_n[2][256];
     const int tid = threadIdx.x;
     const double norm = ((double)B * (double)B - (double)B) * (double)KA;
+    {
+        const int k = tid & 15, sl = tid >> 4;          // 16 slices
+        long long np = 0, nn = 0; double sp = 0.0, sn = 0.0;
+        if (k < KA)
+            for (int p = sl; p < nparts; p += 16) {
+                np += part[p].n_pos[k]; nn += part[p].n_neg[k];
+                sp += part[p].s_pos[k]; sn += part[p].s_neg[k];
+            }
+        r_s[0][tid] = sp; r_s[1][tid] = sn; r_n[0][tid] = np; r_n[1][tid] = nn;
+    }
+    __syncthreads();
     if (tid < KA) {
         long long np = 0, nn = 0; double sp = 0.0, sn = 0.0;
-        for (int p = 0; p < nparts; ++p) {
-            np += part[p].n_pos[tid]; nn += part[p].n_neg[tid];
-            sp += part[p].s_pos[tid]; sn += part[p].s_neg[tid];
+        for (int sl = 0; sl < 16; ++sl) {
+            sp += r_s[0][sl * 16 + tid]; sn += r_s[1][sl * 16 + tid];
+            np += r_n[0][sl * 16 + tid]; nn += r_n[1][sl * 16 + tid];
         }
         double c = 1.0;
         if (activate) {
@@ -350,20 +399,30 @@ extern "C" int raae_style_bn_bwd(const float* dstyles, const float* styles, int 
     RAAE_LAUNCH_RET();
 }
 
+static int rank_grid(int B, int n_aux, int* R) {
+    const int ipb = 32 / n_aux;
+    *R = B > 1024 ? 4 : 1;
+    long groups = (B + (long)ipb * *R - 1) / ((long)ipb * *R);
+    return (int)(groups < RAAE_MAX_PARTS ? groups : RAAE_MAX_PARTS);
+}
+
 extern "C" long raae_rank_loss_work_bytes(int B, int n_aux) {
-    const long nb = (B + 255) / 256;
-    return nb * (long)sizeof(RankWork) + 2L * B * n_aux * (long)sizeof(float) + 256;
+    return (long)RAAE_MAX_PARTS * (long)sizeof(RankWork) + 2L * B * n_aux * (long)sizeof(float) + 256;
 }
 
 extern "C" int raae_rank_loss_fwd_bwd(const float* d, int ldd, const float* z, int ldz, int B, int n_aux, int activate,
                                       void* work, float* loss, float* dz, void* stream) {
     RAAE_CHECK_ARG(d && z && work && loss && B > 1 && n_aux >= 1 && n_aux <= RANK_MAXK && ldd >= n_aux && ldz >= n_aux);
-    const int nb = (B + 255) / 256;
+    int R = 1;
+    const int nb = rank_grid(B, n_aux, &R);
     RankWork* part = (RankWork*)work;
-    float* gpos = (float*)((char*)work + (((size_t)nb * sizeof(RankWork) + 255) & ~(size_t)255));
+    float* gpos = (float*)((char*)work + (((size_t)RAAE_MAX_PARTS * sizeof(RankWork) + 255) & ~(size_t)255));
     float* gneg = gpos + (size_t)B * n_aux;
     hipStream_t st = (hipStream_t)stream;
-#define RANK_CASE(KA) case KA: hipLaunchKernelGGL((rank_pairs_kernel<KA>), dim3(nb), dim3(256), 0, st, d, ldd, z, ldz, B, part, gpos, gneg); break;
+#define RANK_CASE(KA) case KA: \
+        if (R == 1) hipLaunchKernelGGL((rank_pairs_kernel<KA, 1>), dim3(nb), dim3(256), 0, st, d, ldd, z, ldz, B, part, gpos, gneg); \
+        else hipLaunchKernelGGL((rank_pairs_kernel<KA, 4>), dim3(nb), dim3(256), 0, st, d, ldd, z, ldz, B, part, gpos, gneg); \
+        break;
     switch (n_aux) {
         RANK_CASE(1) RANK_CASE(2) RANK_CASE(3) RANK_CASE(4) RANK_CASE(5) RANK_CASE(6) RANK_CASE(7) RANK_CASE(8)
         RANK_CASE(9) RANK_CASE(10) RANK_CASE(11) RANK_CASE(12) RANK_CASE(13) RANK_CASE(14) RANK_CASE(15) RANK_CASE(16)

@@ -32,8 +32,17 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, float* m, float* v,
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const int ns = seg_nslab[i >> 6];
         if (ns == 0) continue;
-        float g = g_slabs[i];
-        for (int s = 1; s < ns; ++s) g += g_slabs[(size_t)s * slab_stride + i];
+        // fixed-order slab sum, 8 independent loads in flight at a time
+        float g = 0.f;
+        int s = 0;
+        for (; s + 8 <= ns; s += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = g_slabs[(size_t)(s + u) * slab_stride + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) g += t[u];
+        }
+        for (; s < ns; ++s) g += g_slabs[(size_t)s * slab_stride + i];
         float pv = p[i];
         if (decoupled) pv = pv * decay; else if (wdf != 0.f) g = g + wdf * pv;
         float mv = m[i], vv = v[i];
@@ -183,3 +192,34 @@ extern "C" int raae_device_info(int* cu_count, int* lds_bytes, char* name, int n
     return 0;
 }
 extern "C" int raae_abi_version(void) { return 1; }
+
+// ---------------------------------------------------------------- data-parallel helper
+namespace {
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* g_slabs, long slab_stride,
+                                                          const unsigned char* seg_nslab, long n, float* out) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int ns = seg_nslab[i >> 6];
+        float g = 0.f;
+        int s = 0;
+        for (; s + 8 <= ns; s += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = g_slabs[(size_t)(s + u) * slab_stride + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) g += t[u];
+        }
+        for (; s < ns; ++s) g += g_slabs[(size_t)s * slab_stride + i];
+        out[i] = g;
+    }
+}
+}  // namespace
+
+extern "C" int raae_slab_reduce(const float* g_slabs, long slab_stride, const unsigned char* seg_nslab, long n,
+                                float* out, void* stream) {
+    RAAE_CHECK_ARG(g_slabs && seg_nslab && out && n > 0 && (n % 64) == 0);
+    long g = (n + 1023) / 1024;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, g_slabs, slab_stride,
+                       seg_nslab, n, out);
+    RAAE_LAUNCH_RET();
+}

@@ -349,11 +349,17 @@ class StepPlan:
 
 
 class StepEngine:
-    def __init__(self, encoder, decoder, discriminator, cfg, device, rng_mode="philox", seed=0, use_graph=True):
+    def __init__(self, encoder, decoder, discriminator, cfg, device, rng_mode="philox", seed=0, use_graph=True,
+                 world_size=1, rank=0, process_group=None):
+        """``world_size > 1``: synchronous data parallelism, one process per GPU over RCCL.  Every rank
+        holds the same parameters, steps its own shard of the global batch (per-replica BatchNorm
+        statistics, rank loss over the local pairs) and the five per-phase gradient arenas are averaged
+        with one all-reduce each.  ``torch.distributed`` must already be initialised."""
         if not torch.cuda.is_available():
             raise RuntimeError("rankaae_amd.engine needs an MI355X (no CPU/PyTorch fallback for the training path)")
         _lib.load()
         self.cfg, self.device = dict(cfg), device
+        self.world_size, self.rank, self.pg = int(world_size), int(rank), process_group
         self.stream = torch.cuda.Stream(device=device)      # hipGraph capture is illegal on the null stream
         self.stream.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(self.stream):
@@ -365,6 +371,11 @@ class StepEngine:
         self.arena = Arena([("disc", discriminator), ("enc", encoder), ("dec", decoder)], device)
         self.max_slab = 256
         self.G = torch.zeros(self.max_slab, self.arena.n, device=device)
+        if self.world_size > 1:
+            self.G_flat = torch.zeros(self.arena.n, device=device)          # all-reduce buffer
+            self.seg_ones = torch.ones(self.arena.n // 64, dtype=torch.uint8, device=device)
+            import torch.distributed as dist
+            dist.broadcast(self.arena.P, src=0, group=self.pg)               # identical initial weights
         from .nets_conv import CompactNet   # local import: conv emitters live in their own module
         if cfg["ae_form"] == "FC":
             self.enc, self.dec = FCNet(encoder, "enc", self), FCNet(decoder, "dec", self)
@@ -389,6 +400,8 @@ class StepEngine:
         self.train_spec = self.train_aux = self.perm = None
         self.phase_hook = None
         self.post_phase_hook = None
+        self._capture = None
+        self.cursor_start, self.cursor_stride, self._cursor_primed = 0, None, False
 
     # -- optimizers: trainer.py:333-397 (only the five that ever step under gradient reversal)
     def _make_optimizers(self):
@@ -426,9 +439,12 @@ class StepEngine:
         self.perm = torch.arange(len(self.train_spec), dtype=torch.int64, device=self.device)
 
     @_on_stream
-    def set_epoch(self, perm, alpha):
+    def set_epoch(self, perm, alpha, start=0, stride=None):
+        """``start``/``stride``: this rank's rows of global batch i are perm[start + i*stride : +b]
+        (single GPU: start 0, stride = b, i.e. consecutive batches)."""
         self.perm.copy_(torch.as_tensor(perm, dtype=torch.int64))
-        self.cursor.zero_()
+        self.cursor_start, self.cursor_stride = int(start), stride
+        self._cursor_primed = False
         self.alpha_dev.fill_(float(alpha))
         self.loss_out[LOSS_SLOTS["mi_accum"]] = 0.0
 
@@ -438,6 +454,7 @@ class StepEngine:
             return self.plans[b]
         P = StepPlan()
         P.b = b
+        P.stride = None
         c, dev, ns = self.cfg, self.device, self.nstyle
         bc = c["batch_size"]
         tape = Tape()
@@ -484,10 +501,34 @@ class StepEngine:
         if self.phase_hook is not None:      # debugging / parity tests: gradients before the update
             self.phase_hook(name, P)
         lo, n = o.lo, o.hi - o.lo
-        ops.adam_step(self.arena.P[lo:], o.m, o.v, self.G[0, lo:], self.arena.n, P.seg[name][lo // 64:], n, o.hyper,
-                      self.steps_dev[o.index:], self.decoupled)
+        if self.world_size > 1:
+            # flat gradient -> RCCL mean over ranks -> Adam on the averaged single slab
+            ops.slab_reduce(self.G[0, lo:], self.arena.n, P.seg[name][lo // 64:], n, self.G_flat[lo:])
+            self._collective(self.G_flat[lo:o.hi])
+            ops.adam_step(self.arena.P[lo:], o.m, o.v, self.G_flat[lo:], self.arena.n, self.seg_ones[lo // 64:], n,
+                          o.hyper, self.steps_dev[o.index:], self.decoupled)
+        else:
+            ops.adam_step(self.arena.P[lo:], o.m, o.v, self.G[0, lo:], self.arena.n, P.seg[name][lo // 64:], n,
+                          o.hyper, self.steps_dev[o.index:], self.decoupled)
         if self.post_phase_hook is not None:  # parity tests: teacher forcing at phase granularity
             self.post_phase_hook(name, P)
+
+    def _all_reduce(self, buf):
+        import torch.distributed as dist
+        dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.pg)
+
+    def _collective(self, buf):
+        """Eager emission: run the all-reduce now.  Under capture: close the current graph segment,
+        remember the collective, open the next segment -- RCCL calls stay outside the hipGraphs."""
+        if self._capture is None:
+            self._all_reduce(buf)
+        else:
+            g = self._capture["cur"]
+            g.end()
+            self._capture["items"] += [g, buf]
+            g = ops.Graph()
+            g.begin()
+            self._capture["cur"] = g
 
     def _begin_phase(self, record):
         self._slab_notes = np.zeros(self.arena.n // 64, dtype=np.uint8) if record else None
@@ -499,7 +540,11 @@ class StepEngine:
         self.tape = P.tape
         tape = P.tape
         mask_bits = 0b01111 | (0b10000 if smooth else 0)
-        ops.step_tick(self.steps_dev, 5, mask_bits, self.rng_counter, self.cursor, b)
+        stride = self.cursor_stride if self.cursor_stride is not None else b
+        if P.stride is None:
+            P.stride = stride
+        assert P.stride == stride, "cursor stride is baked into the captured graph of this batch size"
+        ops.step_tick(self.steps_dev, 5, mask_bits, self.rng_counter, self.cursor, stride)
         if self.rng_mode == "philox":
             ops.rng_fill(tape.buf, tape.seg_desc, tape.seg_scale, len(tape.segs), tape.total, self.seed,
                          self.rng_counter)
@@ -557,6 +602,11 @@ class StepEngine:
     def step(self, b, smooth=True):
         """Run one training step on the next ``b`` rows of the epoch permutation."""
         P = self.plan(b)
+        if not self._cursor_primed:
+            # the tick adds `stride` BEFORE the gather, which reads rows [cursor - b, cursor)
+            stride = self.cursor_stride if self.cursor_stride is not None else b
+            self.cursor.fill_(self.cursor_start + b - stride)
+            self._cursor_primed = True
         if self.rng_mode == "host":
             P.tape.draws, saved = (P.tape.draws if smooth else P.tape.draws[:P.n_draws_no_smooth]), P.tape.draws
             P.tape.fill_host()
@@ -572,12 +622,18 @@ class StepEngine:
             bn_saved = dict(self.bn_counts)
             g = ops.Graph()
             g.begin()
+            self._capture = {"cur": g, "items": []}
             self.emit_step(P, smooth, record=False)
-            g.end()
+            self._capture["cur"].end()
+            P.graphs[key] = self._capture["items"] + [self._capture["cur"]]
+            self._capture = None
             self.bn_counts = bn_saved
-            P.graphs[key] = g
         if self.use_graph:
-            P.graphs[key].launch()
+            for item in P.graphs[key]:
+                if isinstance(item, ops.Graph):
+                    item.launch()
+                else:
+                    self._all_reduce(item)
             self._count_bn_step(smooth)
         else:
             self.emit_step(P, smooth, record=False)

@@ -1,6 +1,277 @@
-"""Emitter for the 1-D-conv networks (``CompactEncoder`` / ``CompactDecoder``)."""
+"""Emitter for the 1-D-conv networks (``CompactEncoder`` / ``CompactDecoder``; reference
+``sc/clustering/model.py:24-174, 264-295, 430-474``): the forward and the explicit backward of
+every residual block as launches of the view-based HIP kernels in ``csrc/raae_conv.hip``.
+
+A tensor is stored raw; PReLU, BatchNorm(affine=False, batch statistics) and the dropout scale
+are applied by whoever reads it (``raae_view_t``), and BatchNorm's backward is folded into the
+prologue of whoever back-propagates through it (``raae_grad_t``).  Block dataflow:
+
+    R  = bn1(X)                          (view of the block input X; bn1 absent for 1 channel / length 1)
+    T1 = conv1(R);  T2 = conv2(bn2(PReLU1(T1)))
+    Sh = conv_short(R)                   (or the identity when shapes match)
+    E1 = fc1(dropout(R)); E2 = fc2(PReLU(E1)); E3 = conv_excit(bn_excit(PReLU(E2)))   (if Cin != Cout)
+    Y  = PReLU2(T2) + PReLUs(Sh) + PReLUe(E3 | E2)
+"""
+import torch
+from torch import nn
+
+from . import ops
+from ._lib import (IN_NONE, OUT_RAW, OUT_STATS_PRELU, OUT_STATS_RAW, OUT_SOFTPLUS, OUT_RELU, G_DIRECT,
+                   RAAE_MAX_PARTS)
+
+
+def _conv_desc(m, Lin):
+    if isinstance(m, nn.ConvTranspose1d):
+        k, s = m.kernel_size[0], m.stride[0]
+        return ops.make_conv(m.in_channels, Lin, m.out_channels, Lin * s, k, s, 0, False, m.groups, True), Lin * s
+    k, s, p = m.kernel_size[0], m.stride[0], m.padding[0]
+    Lout = (Lin + 2 * p - k) // s + 1
+    return ops.make_conv(m.in_channels, Lin, m.out_channels, Lout, k, s, p, m.padding_mode == "replicate",
+                         m.groups, False), Lout
+
+
+class Block:
+    """Static description of one Encoding/DecodingBlock."""
+
+    def __init__(self, m, Lin):
+        self.m = m
+        self.Cin, self.Cout, self.Lin = m.conv1.in_channels, m.conv1.out_channels, Lin
+        self.cv1, self.L1 = _conv_desc(m.conv1, Lin)
+        self.cv2, self.Lout = _conv_desc(m.conv2, self.L1)
+        self.cvs = _conv_desc(m.conv_short, Lin)[0] if m.conv_short is not None else None
+        self.E = m.fc1.out_features
+        assert m.fc1.in_features == Lin and m.fc2.out_features == self.Lout
+        self.cve = _conv_desc(m.conv_excit, self.Lout)[0] if m.conv_excit is not None else None
+        self.p = m.dropout_1.p if m.dropout_1 is not None else 0.0
+        self.bns = [b for b in (m.bn1, m.bn2, m.bn_excit) if b is not None]
+
+    def params(self):
+        return list(self.m.parameters())
 
 
 class CompactNet:
     def __init__(self, module, kind, eng):
-        raise NotImplementedError("compact (conv) networks: HIP conv kernels not wired yet")
+        self.module, self.kind, self.eng = module, kind, eng
+        self.blocks = []
+        if kind == "enc":
+            L = module.lin3.in_features * 8      # dim_in = 256: three blocks 256 -> 64 -> 16 -> 8, 4 channels
+            L = module.main[0].fc1.in_features
+            for m in module.main:
+                blk = Block(m, L)
+                self.blocks.append(blk)
+                L = blk.Lout
+            self.flat = self.blocks[-1].Cout * L
+            assert self.flat == module.lin3.in_features
+            self.in_dim, self.out_dim = self.blocks[0].Lin, module.lin3.out_features
+            self.bn_modules = [b for blk in self.blocks for b in blk.bns] + [module.bn_style]
+        else:
+            L = 1
+            mods = list(module.main)
+            for m in mods[:-3]:
+                blk = Block(m, L)
+                self.blocks.append(blk)
+                L = blk.Lout
+            self.bn_f, self.conv_f, act = mods[-3], mods[-2], mods[-1]
+            self.cvf = _conv_desc(self.conv_f, L)[0]
+            self.act = OUT_RELU if isinstance(act, nn.ReLU) else OUT_SOFTPLUS
+            self.in_dim, self.out_dim = self.blocks[0].Cin, L
+            self.bn_modules = [b for blk in self.blocks for b in blk.bns] + [self.bn_f]
+
+    # ------------------------------------------------------------------ workspaces
+    def alloc(self, b):
+        dev = self.eng.device
+        ws = type("WS", (), {})()
+        ws.b = b
+
+        def t(*shape):
+            return torch.empty(*shape, device=dev)
+
+        def parts(C):
+            return torch.zeros(RAAE_MAX_PARTS, C, 2, dtype=torch.float64, device=dev)
+        ws.blk = []
+        for k in self.blocks:
+            w = type("BW", (), {})()
+            w.T1, w.T2 = t(b, k.Cout, k.L1), t(b, k.Cout, k.Lout)
+            w.Sh = t(b, k.Cout, k.Lout) if k.cvs is not None else None
+            w.E1, w.E2 = t(b, k.Cin, k.E), t(b, k.Cin, k.Lout)
+            w.E3 = t(b, k.Cout, k.Lout) if k.cve is not None else None
+            w.Y = t(b, k.Cout, k.Lout)
+            w.pT1, w.pE2, w.pY = parts(k.Cout), parts(k.Cin), parts(k.Cout)
+            w.nT1 = w.nE2 = w.nY = 0
+            w.dBn2, w.pdBn2 = t(b, k.Cout, k.L1), parts(k.Cout)
+            w.dR, w.pdR = t(b, k.Cin, k.Lin), parts(k.Cin)
+            w.dBnE, w.pdBnE = t(b, k.Cin, k.Lout), parts(k.Cin)
+            w.dE1a = t(b, k.Cin, k.E)
+            w.ndBn2 = w.ndR = w.ndBnE = 0
+            ws.blk.append(w)
+        if self.kind == "enc":
+            ws.zl = t(b, self.out_dim)
+            ws.pzl = parts(self.out_dim)
+            ws.nzl = 0
+            ws.styles, ws.dz = t(b, self.out_dim), t(b, self.out_dim)
+            ws.dYlast = t(b, self.flat)
+            ws.out = ws.styles
+        else:
+            ws.spec = t(b, self.out_dim)
+            ws.dBnF, ws.pdBnF = t(b, self.blocks[-1].Cout, self.out_dim), parts(self.blocks[-1].Cout)
+            ws.ndBnF = 0
+            ws.out = ws.spec
+        return ws
+
+    def mask_slots(self, tape, b, train=True):
+        masks = []
+        for k in self.blocks:
+            if train and k.p > 0:
+                off = tape.slot(b * k.Cin * k.Lin, 1, 1.0 - k.p)
+                tape.draw("mask", off, (b, k.Cin, k.Lin), 1.0 - k.p)
+                masks.append((off, (b, k.Cin, k.Lin)))
+            else:
+                masks.append(None)
+        return masks
+
+    # ------------------------------------------------------------------ helpers
+    def _bn(self, bn, partials, nparts, count, train, update):
+        if train:
+            return ops.make_bn(partials, nparts, count, bn.running_mean, bn.running_var, bn.momentum, bn.eps, update)
+        return ops.make_bn(None, 0, 0, bn.running_mean, bn.running_var, bn.momentum, bn.eps, False)
+
+    def _mask(self, masks, i, train):
+        if train and masks is not None and masks[i] is not None:
+            return self.eng.tape.view(masks[i][0], *masks[i][1])
+        return None
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, ws, x, masks, train=True):
+        b = ws.b
+        X, pX, nX = x, None, 0                # block input (raw), statistics of it
+        for i, (k, w) in enumerate(zip(self.blocks, ws.blk)):
+            m = k.m
+            w.X, w.pX, w.nX = X, pX, nX
+
+            def vR(update, mask=None, k=k, m=m, X=X, pX=pX, nX=nX):
+                bn = self._bn(m.bn1, pX, nX, b * k.Lin, train, update) if m.bn1 is not None else None
+                return ops.make_view(X, None, bn, mask)
+            w.nT1 = ops.conv_fwd(vR(True), b, k.cv1, m.conv1.weight, m.conv1.bias, w.T1, OUT_STATS_PRELU,
+                                 m.relu1.weight, w.pT1)
+            v1 = ops.make_view(w.T1, m.relu1.weight, self._bn(m.bn2, w.pT1, w.nT1, b * k.L1, train, True))
+            ops.conv_fwd(v1, b, k.cv2, m.conv2.weight, m.conv2.bias, w.T2, OUT_RAW)
+            if k.cvs is not None:
+                ops.conv_fwd(vR(False), b, k.cvs, m.conv_short.weight, m.conv_short.bias, w.Sh, OUT_RAW)
+            ops.lenlin_fwd(vR(False, self._mask(masks, i, train)), b, k.Cin, k.Lin, m.fc1.weight, m.fc1.bias, k.E,
+                           w.E1, OUT_RAW)
+            ve1 = ops.make_view(w.E1, m.relu_excit_1.weight)
+            if k.cve is not None:
+                w.nE2 = ops.lenlin_fwd(ve1, b, k.Cin, k.E, m.fc2.weight, m.fc2.bias, k.Lout, w.E2, OUT_STATS_PRELU,
+                                       m.relu_excit_2.weight, w.pE2)
+                ve2 = ops.make_view(w.E2, m.relu_excit_2.weight,
+                                    self._bn(m.bn_excit, w.pE2, w.nE2, b * k.Lout, train, True))
+                ops.conv_fwd(ve2, b, k.cve, m.conv_excit.weight, m.conv_excit.bias, w.E3, OUT_RAW)
+                vc = ops.make_view(w.E3, m.relu_excit_3.weight)
+            else:
+                ops.lenlin_fwd(ve1, b, k.Cin, k.E, m.fc2.weight, m.fc2.bias, k.Lout, w.E2, OUT_RAW)
+                vc = ops.make_view(w.E2, m.relu_excit_2.weight)
+            vb = ops.make_view(w.Sh, m.relu_short.weight) if k.cvs is not None else vR(False)
+            w.nY = ops.sum3_fwd(ops.make_view(w.T2, m.relu2.weight), vb, vc, b, k.Cout, k.Lout, w.Y, w.pY)
+            X, pX, nX = w.Y, w.pY, w.nY
+        last = self.blocks[-1]
+        if self.kind == "enc":
+            mod = self.module
+            ws.nzl = ops.dense_fwd(X.view(b, self.flat), b, self.flat, IN_NONE, None, None, None, mod.lin3.weight,
+                                   mod.lin3.bias, self.out_dim, ws.zl, OUT_STATS_RAW, None, ws.pzl)
+            ops.style_bn_fwd(ws.zl, b, self.out_dim, self._bn(mod.bn_style, ws.pzl, ws.nzl, b, train, True), ws.styles)
+        else:
+            vf = ops.make_view(X, None, self._bn(self.bn_f, pX, nX, b * last.Lout, train, True))
+            ops.conv_fwd(vf, b, self.cvf, self.conv_f.weight, self.conv_f.bias, ws.spec.view(b, 1, self.out_dim),
+                         OUT_RAW, None, None, self.act)
+        if train:
+            self.eng.count_bn(self.bn_modules)
+        return ws.out
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, ws, x, masks, g_out, dx_in=None):
+        eng, b = self.eng, ws.b
+        G = eng.gslab
+        last, wl = self.blocks[-1], ws.blk[-1]
+        if self.kind == "enc":
+            mod = self.module
+            ops.style_bn_bwd(g_out, ws.styles, b, self.out_dim, self._bn(mod.bn_style, ws.pzl, ws.nzl, b, True, False),
+                             ws.dz)
+            ns = ops.dense_bwd(ws.dz, G_DIRECT, None, 0, None, None, None, b, self.out_dim, wl.Y.view(b, self.flat),
+                               self.flat, IN_NONE, None, None, None, mod.lin3.weight, G(mod.lin3.weight),
+                               G(mod.lin3.bias), None, eng.arena.n, ws.dYlast, None)
+            eng.note_slabs([mod.lin3.weight, mod.lin3.bias], ns)
+            gy = dict(g=ws.dYlast.view(b, last.Cout, last.Lout), bn=None, parts=None, nparts=0)
+        else:
+            go = ops.make_grad(g_out.view(b, 1, self.out_dim), raw=ws.spec.view(b, 1, self.out_dim), act=self.act)
+            vf = ops.make_view(wl.Y, None, self._bn(self.bn_f, wl.pY, wl.nY, b * last.Lout, True, False))
+            ops.conv_bwd_weight(go, b, self.cvf, vf, G(self.conv_f.weight), G(self.conv_f.bias), None)
+            eng.note_slabs([self.conv_f.weight, self.conv_f.bias], 1)
+            ws.ndBnF = ops.conv_bwd_data(go, b, self.cvf, self.conv_f.weight, vf, ws.dBnF, False, ws.pdBnF)
+            gy = dict(g=ws.dBnF, bn=self.bn_f, parts=ws.pdBnF, nparts=ws.ndBnF)
+
+        for i in reversed(range(len(self.blocks))):
+            k, w, m = self.blocks[i], ws.blk[i], self.blocks[i].m
+            need_dx = i > 0 or dx_in is not None
+            dR = w.dR if i > 0 else (dx_in.view(b, k.Cin, k.Lin) if dx_in is not None else None)
+            ybn = self._bn(gy["bn"], w.pY, w.nY, b * k.Lout, True, False) if gy["bn"] is not None else None
+
+            def gspec(raw, slope, gy=gy, ybn=ybn, w=w):
+                return ops.make_grad(gy["g"], raw=raw, slope=slope, bn=ybn, g_partials=gy["parts"],
+                                     g_nparts=gy["nparts"], u=w.Y if ybn is not None else None)
+
+            def vR(mask=None, k=k, m=m, w=w):
+                bn = self._bn(m.bn1, w.pX, w.nX, b * k.Lin, True, False) if m.bn1 is not None else None
+                return ops.make_view(w.X, None, bn, mask)
+            # ---- main branch
+            go2 = gspec(w.T2, m.relu2.weight)
+            v1 = ops.make_view(w.T1, m.relu1.weight, self._bn(m.bn2, w.pT1, w.nT1, b * k.L1, True, False))
+            ops.conv_bwd_weight(go2, b, k.cv2, v1, G(m.conv2.weight), G(m.conv2.bias), G(m.relu2.weight))
+            w.ndBn2 = ops.conv_bwd_data(go2, b, k.cv2, m.conv2.weight, v1, w.dBn2, False, w.pdBn2)
+            go1 = ops.make_grad(w.dBn2, raw=w.T1, slope=m.relu1.weight,
+                                bn=self._bn(m.bn2, w.pT1, w.nT1, b * k.L1, True, False), g_partials=w.pdBn2,
+                                g_nparts=w.ndBn2)
+            ops.conv_bwd_weight(go1, b, k.cv1, vR(), G(m.conv1.weight), G(m.conv1.bias), G(m.relu1.weight))
+            touched = [m.conv2.weight, m.conv2.bias, m.relu2.weight, m.conv1.weight, m.conv1.bias, m.relu1.weight]
+            if need_dx:
+                ops.conv_bwd_data(go1, b, k.cv1, m.conv1.weight, vR(), dR, False, None)
+            # ---- shortcut
+            if k.cvs is not None:
+                gos = gspec(w.Sh, m.relu_short.weight)
+                ops.conv_bwd_weight(gos, b, k.cvs, vR(), G(m.conv_short.weight), G(m.conv_short.bias),
+                                    G(m.relu_short.weight))
+                touched += [m.conv_short.weight, m.conv_short.bias, m.relu_short.weight]
+                if need_dx:
+                    ops.conv_bwd_data(gos, b, k.cvs, m.conv_short.weight, vR(), dR, True, None)
+            elif need_dx:
+                ops.grad_materialize(gspec(None, None), b, k.Cout, k.Lout, dR, True, None)
+            # ---- excitation branch
+            ve1 = ops.make_view(w.E1, m.relu_excit_1.weight)
+            if k.cve is not None:
+                goe3 = gspec(w.E3, m.relu_excit_3.weight)
+                bne = self._bn(m.bn_excit, w.pE2, w.nE2, b * k.Lout, True, False)
+                ve2 = ops.make_view(w.E2, m.relu_excit_2.weight, bne)
+                ops.conv_bwd_weight(goe3, b, k.cve, ve2, G(m.conv_excit.weight), G(m.conv_excit.bias),
+                                    G(m.relu_excit_3.weight))
+                w.ndBnE = ops.conv_bwd_data(goe3, b, k.cve, m.conv_excit.weight, ve2, w.dBnE, False, w.pdBnE)
+                goe2 = ops.make_grad(w.dBnE, raw=w.E2, slope=m.relu_excit_2.weight, bn=bne, g_partials=w.pdBnE,
+                                     g_nparts=w.ndBnE)
+                touched += [m.conv_excit.weight, m.conv_excit.bias, m.relu_excit_3.weight]
+            else:
+                goe2 = gspec(w.E2, m.relu_excit_2.weight)
+            ops.lenlin_bwd_weight(goe2, b, k.Cin, k.Lout, ve1, k.E, G(m.fc2.weight), G(m.fc2.bias),
+                                  G(m.relu_excit_2.weight))
+            ops.lenlin_bwd_data(goe2, b, k.Cin, k.Lout, m.fc2.weight, ve1, k.E, w.dE1a, False, None)
+            goe1 = ops.make_grad(w.dE1a, raw=w.E1, slope=m.relu_excit_1.weight)
+            vin = vR(self._mask(masks, i, True))
+            ops.lenlin_bwd_weight(goe1, b, k.Cin, k.E, vin, k.Lin, G(m.fc1.weight), G(m.fc1.bias),
+                                  G(m.relu_excit_1.weight))
+            touched += [m.fc2.weight, m.fc2.bias, m.relu_excit_2.weight, m.fc1.weight, m.fc1.bias,
+                        m.relu_excit_1.weight]
+            if need_dx:
+                w.ndR = ops.lenlin_bwd_data(goe1, b, k.Cin, k.E, m.fc1.weight, vin, k.Lin, dR, True,
+                                            w.pdR if m.bn1 is not None else None)
+            eng.note_slabs(touched, 1)
+            if i > 0:
+                gy = dict(g=w.dR, bn=m.bn1, parts=w.pdR, nparts=w.ndR)
+                if m.bn1 is None:
+                    gy = dict(g=w.dR, bn=None, parts=None, nparts=0)

@@ -135,6 +135,11 @@ def adam_step(p, m, v, g_slabs, slab_stride, seg_nslab, n, hyper, step, decouple
                                      _ptr(step, torch.int32), 1 if decoupled else 0, _stream()), "raae_adam_step")
 
 
+def slab_reduce(g_slabs, slab_stride, seg_nslab, n, out):
+    check(_lib.load().raae_slab_reduce(_ptr(g_slabs), slab_stride, _ptr(seg_nslab, torch.uint8), n, _ptr(out),
+                                       _stream()), "raae_slab_reduce")
+
+
 def step_tick(steps, n, mask, rng_counter, cursor, cursor_inc):
     check(_lib.load().raae_step_tick(_ptr(steps, torch.int32), n, mask, _ptr(rng_counter, torch.int64),
                                      _ptr(cursor, torch.int32), cursor_inc, _stream()), "raae_step_tick")
@@ -180,3 +185,97 @@ class Event:
         ms = C.c_float(0)
         check(_lib.load().raae_event_elapsed_ms(self.h, stop.h, C.byref(ms)), "raae_event_elapsed_ms")
         return ms.value
+
+
+# ------------------------------------------------------------------ conv-network ops
+def make_view(raw, slope=None, bn=None, mask=None):
+    v = _lib.ViewT()
+    v.raw = raw.data_ptr()
+    v.slope = slope.data_ptr() if slope is not None else None
+    if bn is not None:
+        v.bn = bn
+        v.has_bn = 1
+    else:
+        v.has_bn = 0
+    v.mask = mask.data_ptr() if mask is not None else None
+    v._keep = (raw, slope, mask)
+    return v
+
+
+def make_grad(g, raw=None, slope=None, bn=None, g_partials=None, g_nparts=0, u=None, act=0):
+    s = _lib.GradT()
+    s.g = g.data_ptr()
+    s.g_partials = g_partials.data_ptr() if g_partials is not None else None
+    s.g_nparts = int(g_nparts)
+    s.u = u.data_ptr() if u is not None else None
+    if bn is not None:
+        s.bn = bn
+        s.has_bn = 1
+    else:
+        s.has_bn = 0
+    s.raw = raw.data_ptr() if raw is not None else None
+    s.slope = slope.data_ptr() if slope is not None else None
+    s.act = int(act)
+    s._keep = (g, raw, slope, u, g_partials)
+    return s
+
+
+def make_conv(Cin, Lin, Cout, Lout, K, stride, pad, pad_replicate, groups, transposed):
+    c = _lib.ConvT()
+    c.Cin, c.Lin, c.Cout, c.Lout, c.K, c.stride, c.pad = Cin, Lin, Cout, Lout, K, stride, pad
+    c.pad_replicate, c.groups, c.transposed = int(pad_replicate), groups, int(transposed)
+    return c
+
+
+def conv_fwd(view, B, cv, w, bias, out, stats_kind=0, out_slope=None, out_partials=None, act=0):
+    n = C.c_int(0)
+    check(_lib.load().raae_conv_fwd(C.byref(view), B, C.byref(cv), _ptr(w), _ptr(bias), _ptr(out), stats_kind,
+                                    _ptr(out_slope), _ptr(out_partials, torch.float64), C.byref(n), act, _stream()),
+          "raae_conv_fwd")
+    return n.value
+
+
+def conv_bwd_data(go, B, cv, w, view, din, accumulate, din_partials=None):
+    n = C.c_int(0)
+    check(_lib.load().raae_conv_bwd_data(C.byref(go), B, C.byref(cv), _ptr(w), C.byref(view), _ptr(din),
+                                         1 if accumulate else 0, _ptr(din_partials, torch.float64), C.byref(n),
+                                         _stream()), "raae_conv_bwd_data")
+    return n.value
+
+
+def conv_bwd_weight(go, B, cv, view, dw, dbias, dslope=None):
+    check(_lib.load().raae_conv_bwd_weight(C.byref(go), B, C.byref(cv), C.byref(view), _ptr(dw), _ptr(dbias),
+                                           _ptr(dslope), _stream()), "raae_conv_bwd_weight")
+
+
+def lenlin_fwd(view, B, Cc, Lin, w, bias, E, out, stats_kind=0, out_slope=None, out_partials=None):
+    n = C.c_int(0)
+    check(_lib.load().raae_lenlin_fwd(C.byref(view), B, Cc, Lin, _ptr(w), _ptr(bias), E, _ptr(out), stats_kind,
+                                      _ptr(out_slope), _ptr(out_partials, torch.float64), C.byref(n), _stream()),
+          "raae_lenlin_fwd")
+    return n.value
+
+
+def lenlin_bwd_data(go, B, Cc, E, w, view, Lin, din, accumulate, din_partials=None):
+    n = C.c_int(0)
+    check(_lib.load().raae_lenlin_bwd_data(C.byref(go), B, Cc, E, _ptr(w), C.byref(view), Lin, _ptr(din),
+                                           1 if accumulate else 0, _ptr(din_partials, torch.float64), C.byref(n),
+                                           _stream()), "raae_lenlin_bwd_data")
+    return n.value
+
+
+def lenlin_bwd_weight(go, B, Cc, E, view, Lin, dw, dbias, dslope=None):
+    check(_lib.load().raae_lenlin_bwd_weight(C.byref(go), B, Cc, E, C.byref(view), Lin, _ptr(dw), _ptr(dbias),
+                                             _ptr(dslope), _stream()), "raae_lenlin_bwd_weight")
+
+
+def sum3_fwd(va, vb, vc, B, Cc, L, y, out_partials=None):
+    n = C.c_int(0)
+    check(_lib.load().raae_sum3_fwd(C.byref(va), C.byref(vb), C.byref(vc), B, Cc, L, _ptr(y),
+                                    _ptr(out_partials, torch.float64), C.byref(n), _stream()), "raae_sum3_fwd")
+    return n.value
+
+
+def grad_materialize(go, B, Cc, L, draw, accumulate=False, dslope=None):
+    check(_lib.load().raae_grad_materialize(C.byref(go), B, Cc, L, _ptr(draw), 1 if accumulate else 0, _ptr(dslope),
+                                            _stream()), "raae_grad_materialize")

@@ -1,0 +1,188 @@
+"""``Trainer`` -- drop-in for the reference's ``sc/clustering/trainer.py:33-474`` on MI355X.
+
+Same constructor / ``from_data`` / ``train(callback)`` surface, same files written
+(``losses.csv`` rows, ``final.pt`` / ``best.pt`` / ``checkpoints/`` whole-module pickles with the
+reference's dict keys), same per-epoch validation, metrics, model selection and
+``ReduceLROnPlateau`` schedule.  Everything from the batch loop downward (trainer.py:103-268)
+runs as HIP kernels through ``rankaae_amd.engine.StepEngine``; there is no PyTorch/CPU fallback.
+
+Build-only config keys (all optional, defaults preserve reference behaviour):
+  ``rng_mode``  "philox" (device Philox tape, default) | "host" (reference-order CPU draws; parity)
+  ``use_graph`` True: replay one captured hipGraph per step
+  ``seed``      Philox seed (``rng_mode: philox``)
+"""
+import copy
+import itertools
+import logging
+import os
+import shutil
+
+import numpy as np
+import torch
+
+from .dataloader import get_dataloaders
+from .engine import StepEngine
+from .model import AE_CLS_DICT, DiscriminatorFC
+from .parameter import OPTIM_NAMES, Parameters
+
+
+def alpha(epoch_percentage, step=800, limit=0.7):
+    """Gradient-reversal ramp (reference ``sc/utils/functions.py:214-219``)."""
+    return (2. / (1. + np.exp(-1.0E4 / step * epoch_percentage)) - 1) * limit
+
+
+class PlateauScheduler:
+    """``ReduceLROnPlateau(mode="min", threshold_mode="rel", cooldown=0, min_lr=0, eps=1e-8)`` as
+    the reference configures it (trainer.py:400-408), acting on one engine optimizer."""
+
+    def __init__(self, opt, factor, patience, threshold=0.01):
+        self.opt, self.factor, self.patience, self.threshold = opt, factor, patience, threshold
+        self.best, self.num_bad_epochs = float("inf"), 0
+
+    def step(self, metric):
+        metric = float(metric)
+        if metric < self.best * (1.0 - self.threshold):
+            self.best, self.num_bad_epochs = metric, 0
+        else:
+            self.num_bad_epochs += 1
+        if self.num_bad_epochs > self.patience:
+            new_lr = max(self.opt.lr * self.factor, 0.0)
+            if self.opt.lr - new_lr > 1e-8:
+                self.opt.lr = new_lr
+                self.opt.push()
+            self.num_bad_epochs = 0
+
+
+class Trainer:
+    metric_weights = [1.0, -1.0, -0.01, -1.0, -1.0]
+    gau_kernel_size = 17
+
+    def __init__(self, encoder, decoder, discriminator, device, train_loader, val_loader, verbose=True,
+                 work_dir='.', tb_logdir="runs", config_parameters=Parameters({}),
+                 logger=logging.getLogger("training"), loss_logger=logging.getLogger("losses")):
+        self.logger, self.loss_logger = logger, loss_logger
+        self.device = device
+        self.encoder, self.decoder, self.discriminator = encoder, decoder, discriminator
+        self.train_loader, self.val_loader = train_loader, val_loader
+        self.verbose, self.work_dir, self.tb_logdir = verbose, work_dir, tb_logdir
+        self.epoch_stop_smooth = 500
+        self.__dict__.update(config_parameters.to_dict())
+        if not self.gradient_reversal or self.use_cnn_discriminator:
+            raise ValueError("only gradient_reversal: true with DiscriminatorFC is reachable in the reference "
+                             "(SURVEY.md finding 4)")
+        if self.optimizer_name not in OPTIM_NAMES:
+            raise ValueError(f"optimizer_name must be one of {OPTIM_NAMES}")
+        cfg = config_parameters.to_dict()
+        self.engine = StepEngine(encoder, decoder, discriminator, cfg, device,
+                                 rng_mode=cfg.get("rng_mode", "philox"), seed=cfg.get("seed", 0),
+                                 use_graph=cfg.get("use_graph", True))
+        ds = train_loader.dataset
+        if ds.aux is None:
+            raise ValueError("n_aux: 0 is not reachable in the reference (SURVEY.md finding 4)")
+        self.engine.set_data(ds.spec, ds.aux)
+        self.load_optimizers()
+        self.load_schedulers()
+
+    def load_optimizers(self):
+        self.optimizers = self.engine.opts
+
+    def load_schedulers(self):
+        self.schedulers = {name: PlateauScheduler(opt, self.sch_factor, self.sch_patience)
+                           for name, opt in self.optimizers.items()}
+
+    def zerograd(self):
+        """Gradients live in per-phase slabs that every backward overwrites: nothing to clear."""
+
+    def _model_dict(self):
+        """Whole-module pickles under the reference's keys (trainer.py:281-283), detached from the
+        engine's arena so the file holds plain, individually-owned tensors."""
+        self.engine.sync_bn_counters()
+        out = {}
+        for key, mod in (("Encoder", self.encoder), ("Decoder", self.decoder),
+                         ("Style Discriminator", self.discriminator)):
+            m = copy.deepcopy(mod)
+            for p in m.parameters():
+                p.data = p.data.clone()
+            out[key] = m
+        return out
+
+    def train(self, callback=None):
+        from scipy.stats import shapiro, spearmanr
+        eng = self.engine
+        best_combined_metric = 10.0
+        chkpt_dir = f"{self.work_dir}/checkpoints"
+        os.makedirs(chkpt_dir, exist_ok=True)
+        best_chpt_file, metrics = None, None
+        self.loss_logger.info(
+            "Epoch,Train_D,Val_D,Train_G,Val_G,Train_Aux,Val_Aux,Train_Recon,"
+            "Val_Recon,Train_Smooth,Val_Smooth,Train_Mutual_Info,Val_Mutual_Info")
+        vds = self.val_loader.dataset
+        val_spec = torch.as_tensor(vds.spec, dtype=torch.float32).contiguous().to(self.device)
+        val_aux = torch.as_tensor(vds.aux, dtype=torch.float32).contiguous().to(self.device)
+        n_train, bs = len(self.train_loader.dataset), self.train_loader.batch_size
+        n_batch = len(self.train_loader)
+        for epoch in range(self.max_epoch):
+            alpha_ = alpha(epoch / self.max_epoch, self.alpha_flat_step, self.alpha_limit)
+            eng.set_epoch(self.train_loader.epoch_permutation(), alpha_)
+            smooth = epoch < self.epoch_stop_smooth
+            for ib in range(n_batch):
+                eng.step(min(bs, n_train - ib * bs), smooth=smooth)
+            tl = eng.losses()
+            if not smooth:
+                tl["smooth"] = 0.0
+            z, vl = eng.validate(val_spec, val_aux)
+            if epoch % 10 == 0:
+                self.loss_logger.info(
+                    f"{epoch:d},\t"
+                    f"{tl['adversarial']:.6f},\t{vl['adversarial']:.6f},\t"
+                    f"{0.0:.6f},\t{0.0:.6f},\t"
+                    f"{tl['kendall']:.6f},\t{vl['kendall']:.6f},\t"
+                    f"{tl['recon']:.6f},\t{vl['recon']:.6f},\t"
+                    f"{tl['smooth']:.6f},\t{vl['smooth']:.6f},\t"
+                    f"{tl['mutual_info']:.6f},\t{vl['mutual_info']:.6f},\t")
+            avg_mutual_info = tl["mi_accum"] / n_batch
+            style_np = z.detach().cpu().numpy().T
+            style_shapiro = [shapiro(x).statistic for x in style_np]
+            style_coupling = np.max(np.fabs([spearmanr(style_np[j1], style_np[j2]).correlation
+                                             for j1, j2 in itertools.combinations(range(style_np.shape[0]), 2)]))
+            metrics = [min(style_shapiro), vl["recon"], avg_mutual_info, style_coupling, vl["kendall"]]
+            combined_metric = -(np.array(self.metric_weights) * np.array(metrics)).sum()
+            if combined_metric > best_combined_metric:
+                best_combined_metric = combined_metric
+                best_chpt_file = f"{chkpt_dir}/epoch_{epoch:06d}_loss_{combined_metric:07.6g}.pt"
+                torch.save(self._model_dict(), best_chpt_file)
+            for sch in self.schedulers.values():
+                sch.step(combined_metric)
+            if callback is not None:
+                callback(epoch, metrics)
+        torch.save(self._model_dict(), f"{self.work_dir}/final.pt")
+        if best_chpt_file is not None:
+            shutil.copy2(best_chpt_file, f"{self.work_dir}/best.pt")
+        return metrics
+
+    @classmethod
+    def from_data(cls, csv_fn, igpu=0, verbose=True, work_dir='.', train_ratio=0.7, validation_ratio=0.15,
+                  test_ratio=0.15, config_parameters=Parameters({}), logger=logging.getLogger("from_data"),
+                  loss_logger=logging.getLogger("losses"), arrays=None):
+        p = config_parameters
+        assert p.ae_form in AE_CLS_DICT
+        dl_train, dl_val, _ = get_dataloaders(csv_fn, p.batch_size, (train_ratio, validation_ratio, test_ratio),
+                                              n_aux=p.n_aux, arrays=arrays)
+        if not torch.cuda.is_available():
+            raise RuntimeError("rankaae_amd needs an MI355X GPU: the training path has no CPU fallback "
+                               "(the reference would log 'Use Slow CPU!' here)")
+        if verbose:
+            logger.info("Use GPU")
+        device = torch.device(f"cuda:{max(igpu, 0)}")
+        torch.cuda.set_device(device)
+        encoder = AE_CLS_DICT[p.ae_form]["encoder"](nstyle=p.nstyle, dropout_rate=p.dropout_rate, dim_in=p.dim_in,
+                                                    n_layers=p.n_layers)
+        decoder = AE_CLS_DICT[p.ae_form]["decoder"](nstyle=p.nstyle, dropout_rate=p.dropout_rate,
+                                                    last_layer_activation=p.decoder_activation, dim_out=p.dim_out,
+                                                    n_layers=p.n_layers)
+        if p.use_cnn_discriminator:
+            raise ValueError("use_cnn_discriminator: true is broken in the reference (SURVEY.md finding 4)")
+        discriminator = DiscriminatorFC(nstyle=p.nstyle, dropout_rate=p.dis_dropout_rate, noise=p.dis_noise,
+                                        layers=p.FC_discriminator_layers)
+        return cls(encoder, decoder, discriminator, device, dl_train, dl_val, verbose=verbose, work_dir=work_dir,
+                   config_parameters=p, logger=logger, loss_logger=loss_logger)

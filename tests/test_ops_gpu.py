@@ -341,3 +341,160 @@ def test_gather_batch_and_disc_input():
     dst = torch.empty(5, 6, device=DEV)
     ops.scale_by_dev(out[8:], al, -1.0, 30, dst)
     close(dst, -0.25 * out[8:].cpu(), 1e-6, 0, "grl")
+
+
+# ------------------------------------------------------------------ conv-network kernels
+def _sandwich(op_kind, B, Cin, Lin, cfg, seed):
+    """value = mask * BN(PReLU(X)) -> op -> out ; a = PReLU(out) ; y = BN(a) ; loss = sum(y * G)."""
+    g = torch.Generator().manual_seed(seed)
+    X = torch.randn(B, Cin, Lin, generator=g)
+    sX = torch.rand(Cin, generator=g) * 0.4 - 0.1
+    mask = (torch.rand(B, Cin, Lin, generator=g) < 0.9).float() / 0.9
+    if op_kind == "conv":
+        m = torch.nn.Conv1d(Cin, cfg["Cout"], cfg["K"], stride=cfg["s"], padding=cfg["p"],
+                            padding_mode="replicate" if cfg["rep"] else "zeros", groups=cfg["g"])
+    elif op_kind == "convT":
+        m = torch.nn.ConvTranspose1d(Cin, cfg["Cout"], cfg["K"], stride=cfg["K"], groups=cfg["g"])
+    else:
+        m = torch.nn.Linear(Lin, cfg["E"])
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * 0.3)
+    Xr = X.clone().requires_grad_(True)
+    sXr = sX.clone().requires_grad_(True)
+    v = F.batch_norm(F.prelu(Xr, sXr), None, None, training=True, eps=1e-5)
+    v.retain_grad()
+    out = m(v * mask)
+    Cout = out.shape[1]
+    sO = torch.rand(Cout, generator=g) * 0.4 - 0.1
+    sOr = sO.clone().requires_grad_(True)
+    y = F.batch_norm(F.prelu(out, sOr), None, None, training=True, eps=1e-5)
+    G = torch.randn(y.shape, generator=g)
+    (y * G).sum().backward()
+    return dict(X=X, sX=sX, mask=mask, m=m, v=v, out=out, sO=sO, y=y, G=G, dsO=sOr.grad, dv=v.grad)
+
+
+def _partials_of(t):      # [B,C,L] -> [2, C, 2] doubles split in two "workgroups" along B
+    h = max(t.shape[0] // 2, 1)
+    P = torch.zeros(2, t.shape[1], 2, dtype=torch.float64)
+    for i, sl in enumerate((t[:h], t[h:])):
+        P[i, :, 0] = sl.double().sum((0, 2))
+        P[i, :, 1] = (sl.double() ** 2).sum((0, 2))
+    return P
+
+
+CONV_CASES = [
+    ("conv", 64, 1, 256, dict(Cout=4, K=11, s=2, p=5, rep=True, g=1)),
+    ("conv", 37, 4, 128, dict(Cout=4, K=11, s=2, p=5, rep=False, g=1)),
+    ("conv", 16, 4, 64, dict(Cout=4, K=4, s=4, p=0, rep=False, g=4)),
+    ("conv", 16, 4, 16, dict(Cout=4, K=5, s=1, p=2, rep=True, g=1)),
+    ("conv", 16, 8, 64, dict(Cout=4, K=1, s=1, p=0, rep=False, g=4)),
+    ("conv", 9, 6, 8, dict(Cout=8, K=1, s=1, p=0, rep=False, g=2)),
+    ("conv", 8, 4, 256, dict(Cout=4, K=11, s=1, p=5, rep=True, g=1)),
+    ("conv", 8, 4, 256, dict(Cout=1, K=1, s=1, p=0, rep=False, g=1)),
+    ("convT", 16, 6, 1, dict(Cout=8, K=2, g=1)),
+    ("convT", 16, 8, 2, dict(Cout=8, K=4, g=1)),
+    ("convT", 16, 6, 1, dict(Cout=8, K=8, g=2)),
+    ("convT", 16, 8, 8, dict(Cout=4, K=8, g=4)),
+    ("convT", 33, 4, 64, dict(Cout=4, K=2, g=1)),
+    ("lenlin", 40, 4, 64, dict(E=2)),
+    ("lenlin", 40, 1, 256, dict(E=4)),
+    ("lenlin", 40, 8, 2, dict(E=64)),
+    ("lenlin", 40, 6, 1, dict(E=1)),
+]
+
+
+@pytest.mark.parametrize("kind,B,Cin,Lin,cfg", CONV_CASES)
+def test_conv_family_fwd_bwd(kind, B, Cin, Lin, cfg):
+    r = _sandwich(kind, B, Cin, Lin, cfg, seed=B + Cin + Lin)
+    m = r["m"]
+    Xd, sXd, md = dev(r["X"]), dev(r["sX"]), dev(r["mask"])
+    a_in = F.prelu(r["X"], r["sX"])
+    pin = _partials_of(a_in).to(DEV)
+    rm, rv = torch.zeros(Cin, device=DEV), torch.ones(Cin, device=DEV)
+    bn_in = ops.make_bn(pin, 2, B * Lin, rm, rv, update_running=True)
+    view = ops.make_view(Xd, sXd, bn_in, md)
+    w, bias = dev(m.weight.detach()), dev(m.bias.detach())
+    Cout, Lout = r["out"].shape[1], r["out"].shape[2]
+    out = torch.empty(B, Cout, Lout, device=DEV)
+    pout = torch.zeros(_lib.RAAE_MAX_PARTS, Cout, 2, dtype=torch.float64, device=DEV)
+    sOd = dev(r["sO"])
+    if kind == "lenlin":
+        nout = ops.lenlin_fwd(view, B, Cin, Lin, w, bias, cfg["E"], out, _lib.OUT_STATS_PRELU, sOd, pout)
+    else:
+        cv = ops.make_conv(Cin, Lin, Cout, Lout, cfg["K"], cfg.get("s", cfg["K"]), cfg.get("p", 0),
+                           cfg.get("rep", False), cfg["g"], kind == "convT")
+        nout = ops.conv_fwd(view, B, cv, w, bias, out, _lib.OUT_STATS_PRELU, sOd, pout)
+    close(out, r["out"], 2e-5, 2e-5, "out")
+    a_out = F.prelu(r["out"].detach(), r["sO"])
+    tot = pout[:nout].sum(0).cpu()
+    close(tot[:, 0], a_out.double().sum((0, 2)), 1e-5, 1e-4, "sum partials")
+    close(tot[:, 1], (a_out.double() ** 2).sum((0, 2)), 1e-5, 1e-4, "sumsq partials")
+    close(rm, 0.1 * a_in.mean((0, 2)), 1e-4, 1e-6, "running mean")
+
+    # backward: grad spec = (G through BN(PReLU(out)))
+    bn_in.update_running = 0
+    y = r["y"].detach()
+    gp = torch.zeros(2, Cout, 2, dtype=torch.float64)
+    h = max(B // 2, 1)
+    for i, sl in enumerate((slice(0, h), slice(h, B))):
+        gp[i, :, 0] = r["G"][sl].double().sum((0, 2))
+        gp[i, :, 1] = (r["G"][sl].double() * y[sl].double()).sum((0, 2))
+    bn_out = ops.make_bn(pout, nout, B * Lout)
+    go = ops.make_grad(dev(r["G"]), raw=out, slope=sOd, bn=bn_out, g_partials=gp.to(DEV), g_nparts=2)
+    dw, db, ds = torch.zeros_like(w), torch.zeros_like(bias), torch.zeros(Cout, device=DEV)
+    din = torch.full((B, Cin, Lin), 0.5, device=DEV)
+    pdin = torch.zeros(_lib.RAAE_MAX_PARTS, Cin, 2, dtype=torch.float64, device=DEV)
+    if kind == "lenlin":
+        ops.lenlin_bwd_weight(go, B, Cin, cfg["E"], view, Lin, dw, db, ds)
+        nd = ops.lenlin_bwd_data(go, B, Cin, cfg["E"], w, view, Lin, din, True, pdin)
+    else:
+        ops.conv_bwd_weight(go, B, cv, view, dw, db, ds)
+        nd = ops.conv_bwd_data(go, B, cv, w, view, din, True, pdin)
+    scale = float(r["G"].abs().mean()) * (B * Lout) ** 0.5
+    close(dw, m.weight.grad, 5e-4, 5e-5 * scale, "dw")
+    close(db, m.bias.grad, 5e-4, 5e-5 * scale, "dbias")
+    if kind != "lenlin" or True:
+        close(ds, r["dsO"], 5e-4, 5e-5 * scale, "dslope_out")
+    close(din, r["dv"] + 0.5, 5e-4, 5e-5, "din (accumulated onto 0.5)")
+    tot = pdin[:nd].sum(0).cpu()
+    want_din = (r["dv"] + 0.5).double()
+    close(tot[:, 0], want_din.sum((0, 2)), 1e-4, 1e-3, "din partial sum")
+    close(tot[:, 1], (want_din * r["v"].detach().double()).sum((0, 2)), 1e-4, 1e-3, "din*y partial sum")
+
+
+def test_sum3_and_grad_materialize():
+    g = torch.Generator().manual_seed(9)
+    B, Cc, L = 24, 4, 64
+    A, Bt, Ct = (torch.randn(B, Cc, L, generator=g) for _ in range(3))
+    sa, sc = torch.rand(Cc, generator=g) * 0.3, torch.rand(Cc, generator=g) * 0.3
+    Ar, Btr, Ctr = (t.clone().requires_grad_(True) for t in (A, Bt, Ct))
+    sar = sa.clone().requires_grad_(True)
+    yb = F.batch_norm(Btr, None, None, training=True, eps=1e-5)      # identity shortcut: res = bn1(X)
+    Y = F.prelu(Ar, sar) + yb + F.prelu(Ctr, sc)
+    Y.retain_grad()
+    Gn = torch.randn(B, Cc, L, generator=g)
+    Rn = F.batch_norm(Y, None, None, training=True, eps=1e-5)
+    (Rn * Gn).sum().backward()
+    pB = _partials_of(Bt).to(DEV)
+    va = ops.make_view(dev(A), dev(sa))
+    vb = ops.make_view(dev(Bt), None, ops.make_bn(pB, 2, B * L))
+    vc = ops.make_view(dev(Ct), dev(sc))
+    y = torch.empty(B, Cc, L, device=DEV)
+    pY = torch.zeros(_lib.RAAE_MAX_PARTS, Cc, 2, dtype=torch.float64, device=DEV)
+    nY = ops.sum3_fwd(va, vb, vc, B, Cc, L, y, pY)
+    close(y, Y, 1e-5, 1e-5, "Y")
+    # gradient of term A and of the identity term through the next block's BatchNorm
+    gp = torch.zeros(1, Cc, 2, dtype=torch.float64)
+    gp[0, :, 0] = Gn.double().sum((0, 2))
+    gp[0, :, 1] = (Gn.double() * Rn.detach().double()).sum((0, 2))
+    bnY = ops.make_bn(pY, nY, B * L)
+    goA = ops.make_grad(dev(Gn), raw=dev(A), slope=dev(sa), bn=bnY, g_partials=gp.to(DEV), g_nparts=1, u=y)
+    dA, dsa = torch.empty(B, Cc, L, device=DEV), torch.empty(Cc, device=DEV)
+    ops.grad_materialize(goA, B, Cc, L, dA, False, dsa)
+    close(dA, Ar.grad, 2e-4, 2e-5, "dA")
+    close(dsa, sar.grad, 5e-4, 1e-4, "dslope A")
+    goI = ops.make_grad(dev(Gn), bn=bnY, g_partials=gp.to(DEV), g_nparts=1, u=y)
+    acc = torch.ones(B, Cc, L, device=DEV)
+    ops.grad_materialize(goI, B, Cc, L, acc, True, None)
+    close(acc, Y.grad + 1.0, 2e-4, 2e-5, "identity shortcut gradient")
