@@ -193,10 +193,10 @@ int raae_conv_fwd(const raae_view_t* in, int B, const raae_conv_t* cv, const flo
  * to din; din_partials (may be NULL) receives {sum din, sum din*y_in} of the FINAL din (after accumulation). */
 int raae_conv_bwd_data(const raae_grad_t* go, int B, const raae_conv_t* cv, const float* w, const raae_view_t* in,
                        float* din, int accumulate, double* din_partials, int* din_nparts, void* stream);
-/* parameter gradients: dw, dbias (same layouts as w/bias) and dslope [Cout] (may be NULL); final values,
- * one workgroup per element, fixed-order tree => deterministic. */
+/* parameter gradients: dw, dbias (same layouts as w/bias) and dslope [Cout] (may be NULL) as *nslab
+ * fixed-order slabs (slab s at ptr + s*slab_stride), summed by raae_adam_step. */
 int raae_conv_bwd_weight(const raae_grad_t* go, int B, const raae_conv_t* cv, const raae_view_t* in,
-                         float* dw, float* dbias, float* dslope, void* stream);
+                         float* dw, float* dbias, float* dslope, long slab_stride, int* nslab, void* stream);
 
 /* nn.Linear applied along the LENGTH axis of [B][C][Lin] -> [B][C][E] (excitation fc1 / fc2, reference
  * model.py:44-47,89-93,125-128,164-167); out_slope / statistics are per CHANNEL c (PReLU on dim 1). */
@@ -205,16 +205,16 @@ int raae_lenlin_fwd(const raae_view_t* in, int B, int C, int Lin, const float* w
 int raae_lenlin_bwd_data(const raae_grad_t* go, int B, int C, int E, const float* w, const raae_view_t* in, int Lin,
                          float* din, int accumulate, double* din_partials, int* din_nparts, void* stream);
 int raae_lenlin_bwd_weight(const raae_grad_t* go, int B, int C, int E, const raae_view_t* in, int Lin,
-                           float* dw, float* dbias, float* dslope, void* stream);
+                           float* dw, float* dbias, float* dslope, long slab_stride, int* nslab, void* stream);
 
 /* Block output: y = view_a + view_b + view_c (reference model.py:99,173), statistics of y for the next BN. */
 int raae_sum3_fwd(const raae_view_t* a, const raae_view_t* b, const raae_view_t* c, int B, int C, int L, float* y,
                   double* out_partials, int* out_nparts, void* stream);
 /* dRaw of a grad spec written (accumulate = 0) or added (accumulate != 0) to `draw` -- the identity
  * shortcut of a block without conv_short (model.py:83), and the gradient handed to a dense layer;
- * dslope (may be NULL): final PReLU-slope gradient [C]. */
+ * dslope (may be NULL): PReLU-slope gradient [C] as *nslab slabs. */
 int raae_grad_materialize(const raae_grad_t* go, int B, int C, int L, float* draw, int accumulate, float* dslope,
-                          void* stream);
+                          long slab_stride, int* nslab, void* stream);
 
 /* Data parallel (replaces the reference's ipyparallel trial farm, sc/cmd/train_sc.py:25-45, per the
  * north star): out[i] = fixed-order sum of the slabs of element i -- the flat gradient that is then

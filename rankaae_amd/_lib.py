@@ -71,12 +71,12 @@ SIGNATURES = {
     "raae_adam_step": (_I, [_P, _P, _P, _P, _L, _P, _L, _P, _P, _I, _P]),
     "raae_conv_fwd": (_I, [_PV, _I, _PC, _P, _P, _P, _I, _P, _P, _PI, _I, _P]),
     "raae_conv_bwd_data": (_I, [_PG, _I, _PC, _P, _PV, _P, _I, _P, _PI, _P]),
-    "raae_conv_bwd_weight": (_I, [_PG, _I, _PC, _PV, _P, _P, _P, _P]),
+    "raae_conv_bwd_weight": (_I, [_PG, _I, _PC, _PV, _P, _P, _P, _L, _PI, _P]),
     "raae_lenlin_fwd": (_I, [_PV, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P, _PI, _P]),
     "raae_lenlin_bwd_data": (_I, [_PG, _I, _I, _I, _P, _PV, _I, _P, _I, _P, _PI, _P]),
-    "raae_lenlin_bwd_weight": (_I, [_PG, _I, _I, _I, _PV, _I, _P, _P, _P, _P]),
+    "raae_lenlin_bwd_weight": (_I, [_PG, _I, _I, _I, _PV, _I, _P, _P, _P, _L, _PI, _P]),
     "raae_sum3_fwd": (_I, [_PV, _PV, _PV, _I, _I, _I, _P, _P, _PI, _P]),
-    "raae_grad_materialize": (_I, [_PG, _I, _I, _I, _P, _I, _P, _P]),
+    "raae_grad_materialize": (_I, [_PG, _I, _I, _I, _P, _I, _P, _L, _PI, _P]),
     "raae_slab_reduce": (_I, [_P, _L, _P, _L, _P, _P]),
     "raae_step_tick": (_I, [_P, _I, C.c_uint, _P, _P, _I, _P]),
     "raae_rng_fill": (_I, [_P, _P, _P, _I, _L, C.c_ulonglong, _P, _P]),

@@ -447,6 +447,8 @@ __global__ __launch_bounds__(256) void grad_materialize_kernel(GradMatArgs a) {
     }
 }
 
+#include "raae_conv_tiled.inc"
+
 int slices_for(long per_channel, int C) {
     long n = (per_channel + 255) / 256;
     long cap = RAAE_MAX_PARTS;
@@ -470,6 +472,20 @@ bool conv_ok(const raae_conv_t* cv) {
     if (cv->transposed) return cv->K == cv->stride && cv->pad == 0 && cv->Lout == cv->Lin * cv->stride;
     return cv->Lout == (cv->Lin + 2 * cv->pad - cv->K) / cv->stride + 1;
 }
+int conv_nw(const raae_conv_t* cv) {
+    return cv->transposed ? cv->Cin * (cv->Cout / cv->groups) * cv->K : cv->Cout * (cv->Cin / cv->groups) * cv->K;
+}
+// samples per tile: enough outputs to occupy 256 threads, bounded by an LDS budget
+int pick_S(long floats_per_sample, long outputs_per_sample, int B, long lds_budget_floats, int min_out) {
+    long S = (min_out + outputs_per_sample - 1) / outputs_per_sample;
+    if (S < 1) S = 1;
+    const long cap = lds_budget_floats / (floats_per_sample > 0 ? floats_per_sample : 1);
+    if (S > cap) S = cap;
+    if (S > B) S = B;
+    if (S < 1) S = 1;
+    return (int)S;
+}
+const long kTileBudget = 10 * 1024;    // floats (40 KB) of dynamic LDS for staged tiles
 
 }  // namespace
 
@@ -482,6 +498,19 @@ extern "C" int raae_conv_fwd(const raae_view_t* in, int B, const raae_conv_t* cv
     ConvFwdArgs a;
     a.in = *in; a.B = B; a.cv = *cv; a.w = w; a.bias = bias; a.out = out; a.stats_kind = stats_kind;
     a.out_slope = out_slope; a.out_partials = out_partials; a.act = act;
+    const long per_in = (long)cv->Cin * (cv->Lin + 2 * (cv->transposed ? 0 : cv->pad));
+    if (conv_nw(cv) <= 1024 && (stats_kind == RAAE_OUT_RAW || cv->Cout <= CT_MAXCH) && per_in <= kTileBudget) {
+        ConvFwdTArgs t;
+        t.a = a;
+        t.S = pick_S(per_in, (long)cv->Cout * cv->Lout, B, kTileBudget, 256);
+        t.ngroups = (B + t.S - 1) / t.S;
+        const int grid = t.ngroups < RAAE_MAX_PARTS ? t.ngroups : RAAE_MAX_PARTS;
+        t.a.nsl = grid;
+        if (out_nparts) *out_nparts = grid;
+        hipLaunchKernelGGL(conv_fwd_tiled_kernel, dim3(grid), dim3(256), sizeof(float) * t.S * per_in,
+                           (hipStream_t)stream, t);
+        RAAE_LAUNCH_RET();
+    }
     a.nsl = slices_for((long)B * cv->Lout, cv->Cout);
     if (out_nparts) *out_nparts = a.nsl;
     hipLaunchKernelGGL(conv_fwd_kernel, dim3(a.nsl * cv->Cout), dim3(256), 0, (hipStream_t)stream, a);
@@ -496,6 +525,19 @@ extern "C" int raae_conv_bwd_data(const raae_grad_t* go, int B, const raae_conv_
     ConvBwdDataArgs a;
     a.go = *go; a.B = B; a.cv = *cv; a.w = w; a.in = *in; a.din = din; a.accumulate = accumulate;
     a.din_partials = din_partials;
+    const long per_g = (long)cv->Cout * cv->Lout;
+    if (conv_nw(cv) <= 1024 && (!din_partials || cv->Cin <= CT_MAXCH) && per_g <= kTileBudget) {
+        ConvBwdDataTArgs t;
+        t.a = a;
+        t.S = pick_S(per_g, (long)cv->Cin * cv->Lin, B, kTileBudget, 256);
+        t.ngroups = (B + t.S - 1) / t.S;
+        const int grid = t.ngroups < RAAE_MAX_PARTS ? t.ngroups : RAAE_MAX_PARTS;
+        t.a.nsl = grid;
+        if (din_nparts) *din_nparts = grid;
+        hipLaunchKernelGGL(conv_bwd_data_tiled_kernel, dim3(grid), dim3(256), sizeof(float) * t.S * per_g,
+                           (hipStream_t)stream, t);
+        RAAE_LAUNCH_RET();
+    }
     a.nsl = slices_for((long)B * cv->Lin, cv->Cin);
     if (din_nparts) *din_nparts = a.nsl;
     hipLaunchKernelGGL(conv_bwd_data_kernel, dim3(a.nsl * cv->Cin), dim3(256), 0, (hipStream_t)stream, a);
@@ -503,12 +545,27 @@ extern "C" int raae_conv_bwd_data(const raae_grad_t* go, int B, const raae_conv_
 }
 
 extern "C" int raae_conv_bwd_weight(const raae_grad_t* go, int B, const raae_conv_t* cv, const raae_view_t* in,
-                                    float* dw, float* dbias, float* dslope, void* stream) {
+                                    float* dw, float* dbias, float* dslope, long slab_stride, int* nslab,
+                                    void* stream) {
     RAAE_CHECK_ARG(conv_ok(cv) && grad_ok(go, cv->Cout) && view_ok(in, cv->Cin) && dw && dbias && B > 0);
     RAAE_CHECK_ARG(!dslope || go->slope);
     ConvBwdWArgs a;
     a.go = *go; a.B = B; a.cv = *cv; a.in = *in; a.dw = dw; a.dbias = dbias; a.dslope = dslope;
-    a.nw = cv->transposed ? cv->Cin * (cv->Cout / cv->groups) * cv->K : cv->Cout * (cv->Cin / cv->groups) * cv->K;
+    a.nw = conv_nw(cv);
+    const long per = (long)(dslope ? 2 : 1) * cv->Cout * cv->Lout + (long)cv->Cin * (cv->Lin + 2 * (cv->transposed ? 0 : cv->pad));
+    if (a.nw <= 1024 && cv->Cout <= 8 && per <= kTileBudget) {
+        ConvBwdWTArgs t;
+        t.a = a; t.slab_stride = slab_stride;
+        const long span = cv->transposed ? cv->Lin : cv->Lout;      // inner-loop trip count per sample
+        t.S = pick_S(per, span, B, kTileBudget, 256);
+        t.ngroups = (B + t.S - 1) / t.S;
+        const int grid = t.ngroups < 64 ? t.ngroups : 64;
+        if (nslab) *nslab = grid;
+        hipLaunchKernelGGL(conv_bwd_weight_tiled_kernel, dim3(grid), dim3(256), sizeof(float) * t.S * per,
+                           (hipStream_t)stream, t);
+        RAAE_LAUNCH_RET();
+    }
+    if (nslab) *nslab = 1;
     hipLaunchKernelGGL(conv_bwd_weight_kernel, dim3(a.nw + 2 * cv->Cout), dim3(256), 0, (hipStream_t)stream, a);
     RAAE_LAUNCH_RET();
 }
@@ -522,6 +579,19 @@ extern "C" int raae_lenlin_fwd(const raae_view_t* in, int B, int C, int Lin, con
     LenLinFwdArgs a;
     a.in = *in; a.B = B; a.C = C; a.Lin = Lin; a.w = w; a.bias = bias; a.E = E; a.out = out;
     a.stats_kind = stats_kind; a.out_slope = out_slope; a.out_partials = out_partials;
+    const long wfl = (long)E * Lin + E, per = (long)C * Lin;
+    if ((stats_kind == RAAE_OUT_RAW || C <= CT_MAXCH) && wfl <= 2048 && per <= kTileBudget - wfl) {
+        LenLinFwdTArgs t;
+        t.a = a;
+        t.S = pick_S(per, (long)C * E, B, kTileBudget - wfl, Lin >= 32 ? 32 : 256);
+        t.ngroups = (B + t.S - 1) / t.S;
+        const int grid = t.ngroups < RAAE_MAX_PARTS ? t.ngroups : RAAE_MAX_PARTS;
+        t.a.nsl = grid;
+        if (out_nparts) *out_nparts = grid;
+        hipLaunchKernelGGL(lenlin_fwd_tiled_kernel, dim3(grid), dim3(256), sizeof(float) * (t.S * per + wfl),
+                           (hipStream_t)stream, t);
+        RAAE_LAUNCH_RET();
+    }
     a.nsl = slices_for((long)B * E, C);
     if (out_nparts) *out_nparts = a.nsl;
     hipLaunchKernelGGL(lenlin_fwd_kernel, dim3(a.nsl * C), dim3(256), 0, (hipStream_t)stream, a);
@@ -536,6 +606,19 @@ extern "C" int raae_lenlin_bwd_data(const raae_grad_t* go, int B, int C, int E, 
     LenLinBwdDataArgs a;
     a.go = *go; a.B = B; a.C = C; a.E = E; a.w = w; a.in = *in; a.Lin = Lin; a.din = din; a.accumulate = accumulate;
     a.din_partials = din_partials;
+    const long wfl = (long)E * Lin, per = (long)C * E;
+    if ((!din_partials || C <= CT_MAXCH) && wfl <= 2048 && per <= kTileBudget - wfl) {
+        LenLinBwdDataTArgs t;
+        t.a = a;
+        t.S = pick_S(per, (long)C * Lin, B, kTileBudget - wfl, (E >= 32 && Lin <= 8) ? 32 : 256);
+        t.ngroups = (B + t.S - 1) / t.S;
+        const int grid = t.ngroups < RAAE_MAX_PARTS ? t.ngroups : RAAE_MAX_PARTS;
+        t.a.nsl = grid;
+        if (din_nparts) *din_nparts = grid;
+        hipLaunchKernelGGL(lenlin_bwd_data_tiled_kernel, dim3(grid), dim3(256), sizeof(float) * (t.S * per + wfl),
+                           (hipStream_t)stream, t);
+        RAAE_LAUNCH_RET();
+    }
     a.nsl = slices_for((long)B * Lin, C);
     if (din_nparts) *din_nparts = a.nsl;
     hipLaunchKernelGGL(lenlin_bwd_data_kernel, dim3(a.nsl * C), dim3(256), 0, (hipStream_t)stream, a);
@@ -543,11 +626,25 @@ extern "C" int raae_lenlin_bwd_data(const raae_grad_t* go, int B, int C, int E, 
 }
 
 extern "C" int raae_lenlin_bwd_weight(const raae_grad_t* go, int B, int C, int E, const raae_view_t* in, int Lin,
-                                      float* dw, float* dbias, float* dslope, void* stream) {
+                                      float* dw, float* dbias, float* dslope, long slab_stride, int* nslab,
+                                      void* stream) {
     RAAE_CHECK_ARG(grad_ok(go, C) && view_ok(in, C) && dw && dbias && B > 0 && E > 0 && Lin > 0);
     RAAE_CHECK_ARG(!dslope || go->slope);
     LenLinBwdWArgs a;
     a.go = *go; a.B = B; a.C = C; a.E = E; a.in = *in; a.Lin = Lin; a.dw = dw; a.dbias = dbias; a.dslope = dslope;
+    const long per = (long)(dslope ? 2 : 1) * C * E + (long)C * Lin;
+    if ((long)E * Lin <= 1024 && E <= 256 && C <= CT_MAXCH && per <= kTileBudget) {
+        LenLinBwdWTArgs t;
+        t.a = a; t.slab_stride = slab_stride;
+        t.S = pick_S(per, C, B, kTileBudget, 64);             // >= 64 rows (s, c) per staging
+        t.ngroups = (B + t.S - 1) / t.S;
+        const int grid = t.ngroups < 64 ? t.ngroups : 64;
+        if (nslab) *nslab = grid;
+        hipLaunchKernelGGL(lenlin_bwd_weight_tiled_kernel, dim3(grid), dim3(256), sizeof(float) * t.S * per,
+                           (hipStream_t)stream, t);
+        RAAE_LAUNCH_RET();
+    }
+    if (nslab) *nslab = 1;
     hipLaunchKernelGGL(lenlin_bwd_weight_kernel, dim3(E * Lin + E + C), dim3(256), 0, (hipStream_t)stream, a);
     RAAE_LAUNCH_RET();
 }
@@ -564,11 +661,16 @@ extern "C" int raae_sum3_fwd(const raae_view_t* a_, const raae_view_t* b_, const
 }
 
 extern "C" int raae_grad_materialize(const raae_grad_t* go, int B, int C, int L, float* draw, int accumulate,
-                                     float* dslope, void* stream) {
+                                     float* dslope, long slab_stride, int* nslab, void* stream) {
     RAAE_CHECK_ARG(grad_ok(go, C) && (draw || dslope) && B > 0 && L > 0 && C > 0);
     RAAE_CHECK_ARG(!dslope || go->slope);
-    GradMatArgs a;
-    a.go = *go; a.B = B; a.C = C; a.L = L; a.draw = draw; a.dslope = dslope; a.accumulate = accumulate;
-    hipLaunchKernelGGL(grad_materialize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, a);
+    GradMatTArgs t;
+    t.a.go = *go; t.a.B = B; t.a.C = C; t.a.L = L; t.a.draw = draw; t.a.dslope = dslope; t.a.accumulate = accumulate;
+    long n = ((long)B * L + 1023) / 1024;
+    if (n > 64) n = 64;
+    if (n < 1) n = 1;
+    t.nsl = (int)n; t.slab_stride = slab_stride;
+    if (nslab) *nslab = t.nsl;
+    hipLaunchKernelGGL(grad_materialize_sliced_kernel, dim3(t.nsl * C), dim3(256), 0, (hipStream_t)stream, t);
     RAAE_LAUNCH_RET();
 }

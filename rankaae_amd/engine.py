@@ -401,6 +401,9 @@ class StepEngine:
         self.phase_hook = None
         self.post_phase_hook = None
         self._capture = None
+        n_side = int(self.cfg.get("side_streams", 3))
+        self.side_streams = [torch.cuda.Stream(device=device) for _ in range(n_side)]
+        self._side_i, self._side_used = 0, set()
         self.cursor_start, self.cursor_stride, self._cursor_primed = 0, None, False
 
     # -- optimizers: trainer.py:333-397 (only the five that ever step under gradient reversal)
@@ -416,6 +419,33 @@ class StepEngine:
                 ("mutual_info", r["enc"][0], r["dec"][1], c["lr_ratio_Mutual"] * lr, (0.9, 0.999), default_wd),
                 ("smoothness", r["dec"][0], r["dec"][1], c["lr_ratio_Smooth"] * lr, (0.9, 0.999), c["weight_decay"])]
         self.opts = {n: OptState(i, n, lo, hi, l, b, 1e-8, wd, self.device) for i, (n, lo, hi, l, b, wd) in enumerate(spec)}
+
+    # -- parameter-gradient kernels run on side streams (parallel branches of the captured graph):
+    #    they are off the critical path of the data-gradient chain and only Adam needs their slabs.
+    def side_stream(self):
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            if not self.side_streams:
+                yield
+                return
+            s = self.side_streams[self._side_i % len(self.side_streams)]
+            self._side_i += 1
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            s.wait_event(ev)
+            self._side_used.add(s)
+            with torch.cuda.stream(s):
+                yield
+        return ctx()
+
+    def join_side_streams(self):
+        for s in list(self._side_used):
+            ev = torch.cuda.Event()
+            ev.record(s)
+            torch.cuda.current_stream().wait_event(ev)
+        self._side_used.clear()
 
     # -- helpers used by the net emitters
     def gslab(self, p):
@@ -498,6 +528,7 @@ class StepEngine:
         o = self.opts[name]
         if notes_host is not None:
             P.seg[name].copy_(torch.from_numpy(notes_host))
+        self.join_side_streams()
         if self.phase_hook is not None:      # debugging / parity tests: gradients before the update
             self.phase_hook(name, P)
         lo, n = o.lo, o.hi - o.lo

@@ -140,6 +140,22 @@ class CompactNet:
             return self.eng.tape.view(masks[i][0], *masks[i][1])
         return None
 
+    def _cw(self, go, b, cv, view, conv, prelu):
+        """conv parameter gradients -> slabs; records the slab count of every tensor written."""
+        eng = self.eng
+        ps = [conv.weight, conv.bias] + ([prelu.weight] if prelu is not None else [])
+        with eng.side_stream():
+            ns = ops.conv_bwd_weight(go, b, cv, view, eng.gslab(conv.weight), eng.gslab(conv.bias),
+                                     eng.gslab(prelu.weight) if prelu is not None else None, eng.arena.n)
+        eng.note_slabs(ps, ns)
+
+    def _lw(self, go, b, Cc, E, view, Lin, lin, prelu):
+        eng = self.eng
+        with eng.side_stream():
+            ns = ops.lenlin_bwd_weight(go, b, Cc, E, view, Lin, eng.gslab(lin.weight), eng.gslab(lin.bias),
+                                       eng.gslab(prelu.weight), eng.arena.n)
+        eng.note_slabs([lin.weight, lin.bias, prelu.weight], ns)
+
     # ------------------------------------------------------------------ forward
     def forward(self, ws, x, masks, train=True):
         b = ws.b
@@ -204,8 +220,7 @@ class CompactNet:
         else:
             go = ops.make_grad(g_out.view(b, 1, self.out_dim), raw=ws.spec.view(b, 1, self.out_dim), act=self.act)
             vf = ops.make_view(wl.Y, None, self._bn(self.bn_f, wl.pY, wl.nY, b * last.Lout, True, False))
-            ops.conv_bwd_weight(go, b, self.cvf, vf, G(self.conv_f.weight), G(self.conv_f.bias), None)
-            eng.note_slabs([self.conv_f.weight, self.conv_f.bias], 1)
+            self._cw(go, b, self.cvf, vf, self.conv_f, None)
             ws.ndBnF = ops.conv_bwd_data(go, b, self.cvf, self.conv_f.weight, vf, ws.dBnF, False, ws.pdBnF)
             gy = dict(g=ws.dBnF, bn=self.bn_f, parts=ws.pdBnF, nparts=ws.ndBnF)
 
@@ -225,52 +240,42 @@ class CompactNet:
             # ---- main branch
             go2 = gspec(w.T2, m.relu2.weight)
             v1 = ops.make_view(w.T1, m.relu1.weight, self._bn(m.bn2, w.pT1, w.nT1, b * k.L1, True, False))
-            ops.conv_bwd_weight(go2, b, k.cv2, v1, G(m.conv2.weight), G(m.conv2.bias), G(m.relu2.weight))
+            self._cw(go2, b, k.cv2, v1, m.conv2, m.relu2)
             w.ndBn2 = ops.conv_bwd_data(go2, b, k.cv2, m.conv2.weight, v1, w.dBn2, False, w.pdBn2)
             go1 = ops.make_grad(w.dBn2, raw=w.T1, slope=m.relu1.weight,
                                 bn=self._bn(m.bn2, w.pT1, w.nT1, b * k.L1, True, False), g_partials=w.pdBn2,
                                 g_nparts=w.ndBn2)
-            ops.conv_bwd_weight(go1, b, k.cv1, vR(), G(m.conv1.weight), G(m.conv1.bias), G(m.relu1.weight))
-            touched = [m.conv2.weight, m.conv2.bias, m.relu2.weight, m.conv1.weight, m.conv1.bias, m.relu1.weight]
+            self._cw(go1, b, k.cv1, vR(), m.conv1, m.relu1)
             if need_dx:
                 ops.conv_bwd_data(go1, b, k.cv1, m.conv1.weight, vR(), dR, False, None)
             # ---- shortcut
             if k.cvs is not None:
                 gos = gspec(w.Sh, m.relu_short.weight)
-                ops.conv_bwd_weight(gos, b, k.cvs, vR(), G(m.conv_short.weight), G(m.conv_short.bias),
-                                    G(m.relu_short.weight))
-                touched += [m.conv_short.weight, m.conv_short.bias, m.relu_short.weight]
+                self._cw(gos, b, k.cvs, vR(), m.conv_short, m.relu_short)
                 if need_dx:
                     ops.conv_bwd_data(gos, b, k.cvs, m.conv_short.weight, vR(), dR, True, None)
             elif need_dx:
-                ops.grad_materialize(gspec(None, None), b, k.Cout, k.Lout, dR, True, None)
+                ops.grad_materialize(gspec(None, None), b, k.Cout, k.Lout, dR, True, None, 0)
             # ---- excitation branch
             ve1 = ops.make_view(w.E1, m.relu_excit_1.weight)
             if k.cve is not None:
                 goe3 = gspec(w.E3, m.relu_excit_3.weight)
                 bne = self._bn(m.bn_excit, w.pE2, w.nE2, b * k.Lout, True, False)
                 ve2 = ops.make_view(w.E2, m.relu_excit_2.weight, bne)
-                ops.conv_bwd_weight(goe3, b, k.cve, ve2, G(m.conv_excit.weight), G(m.conv_excit.bias),
-                                    G(m.relu_excit_3.weight))
+                self._cw(goe3, b, k.cve, ve2, m.conv_excit, m.relu_excit_3)
                 w.ndBnE = ops.conv_bwd_data(goe3, b, k.cve, m.conv_excit.weight, ve2, w.dBnE, False, w.pdBnE)
                 goe2 = ops.make_grad(w.dBnE, raw=w.E2, slope=m.relu_excit_2.weight, bn=bne, g_partials=w.pdBnE,
                                      g_nparts=w.ndBnE)
-                touched += [m.conv_excit.weight, m.conv_excit.bias, m.relu_excit_3.weight]
             else:
                 goe2 = gspec(w.E2, m.relu_excit_2.weight)
-            ops.lenlin_bwd_weight(goe2, b, k.Cin, k.Lout, ve1, k.E, G(m.fc2.weight), G(m.fc2.bias),
-                                  G(m.relu_excit_2.weight))
+            self._lw(goe2, b, k.Cin, k.Lout, ve1, k.E, m.fc2, m.relu_excit_2)
             ops.lenlin_bwd_data(goe2, b, k.Cin, k.Lout, m.fc2.weight, ve1, k.E, w.dE1a, False, None)
             goe1 = ops.make_grad(w.dE1a, raw=w.E1, slope=m.relu_excit_1.weight)
             vin = vR(self._mask(masks, i, True))
-            ops.lenlin_bwd_weight(goe1, b, k.Cin, k.E, vin, k.Lin, G(m.fc1.weight), G(m.fc1.bias),
-                                  G(m.relu_excit_1.weight))
-            touched += [m.fc2.weight, m.fc2.bias, m.relu_excit_2.weight, m.fc1.weight, m.fc1.bias,
-                        m.relu_excit_1.weight]
+            self._lw(goe1, b, k.Cin, k.E, vin, k.Lin, m.fc1, m.relu_excit_1)
             if need_dx:
                 w.ndR = ops.lenlin_bwd_data(goe1, b, k.Cin, k.E, m.fc1.weight, vin, k.Lin, dR, True,
                                             w.pdR if m.bn1 is not None else None)
-            eng.note_slabs(touched, 1)
             if i > 0:
                 gy = dict(g=w.dR, bn=m.bn1, parts=w.pdR, nparts=w.ndR)
                 if m.bn1 is None:

@@ -243,9 +243,11 @@ def conv_bwd_data(go, B, cv, w, view, din, accumulate, din_partials=None):
     return n.value
 
 
-def conv_bwd_weight(go, B, cv, view, dw, dbias, dslope=None):
+def conv_bwd_weight(go, B, cv, view, dw, dbias, dslope, slab_stride):
+    n = C.c_int(0)
     check(_lib.load().raae_conv_bwd_weight(C.byref(go), B, C.byref(cv), C.byref(view), _ptr(dw), _ptr(dbias),
-                                           _ptr(dslope), _stream()), "raae_conv_bwd_weight")
+                                           _ptr(dslope), slab_stride, C.byref(n), _stream()), "raae_conv_bwd_weight")
+    return n.value
 
 
 def lenlin_fwd(view, B, Cc, Lin, w, bias, E, out, stats_kind=0, out_slope=None, out_partials=None):
@@ -264,9 +266,12 @@ def lenlin_bwd_data(go, B, Cc, E, w, view, Lin, din, accumulate, din_partials=No
     return n.value
 
 
-def lenlin_bwd_weight(go, B, Cc, E, view, Lin, dw, dbias, dslope=None):
+def lenlin_bwd_weight(go, B, Cc, E, view, Lin, dw, dbias, dslope, slab_stride):
+    n = C.c_int(0)
     check(_lib.load().raae_lenlin_bwd_weight(C.byref(go), B, Cc, E, C.byref(view), Lin, _ptr(dw), _ptr(dbias),
-                                             _ptr(dslope), _stream()), "raae_lenlin_bwd_weight")
+                                             _ptr(dslope), slab_stride, C.byref(n), _stream()),
+          "raae_lenlin_bwd_weight")
+    return n.value
 
 
 def sum3_fwd(va, vb, vc, B, Cc, L, y, out_partials=None):
@@ -276,6 +281,8 @@ def sum3_fwd(va, vb, vc, B, Cc, L, y, out_partials=None):
     return n.value
 
 
-def grad_materialize(go, B, Cc, L, draw, accumulate=False, dslope=None):
+def grad_materialize(go, B, Cc, L, draw, accumulate=False, dslope=None, slab_stride=0):
+    n = C.c_int(0)
     check(_lib.load().raae_grad_materialize(C.byref(go), B, Cc, L, _ptr(draw), 1 if accumulate else 0, _ptr(dslope),
-                                            _stream()), "raae_grad_materialize")
+                                            slab_stride, C.byref(n), _stream()), "raae_grad_materialize")
+    return n.value

@@ -442,15 +442,19 @@ def test_conv_family_fwd_bwd(kind, B, Cin, Lin, cfg):
         gp[i, :, 1] = (r["G"][sl].double() * y[sl].double()).sum((0, 2))
     bn_out = ops.make_bn(pout, nout, B * Lout)
     go = ops.make_grad(dev(r["G"]), raw=out, slope=sOd, bn=bn_out, g_partials=gp.to(DEV), g_nparts=2)
-    dw, db, ds = torch.zeros_like(w), torch.zeros_like(bias), torch.zeros(Cout, device=DEV)
+    nwp, stride = (w.numel() + 63) // 64 * 64, (w.numel() + 63) // 64 * 64 + 128
+    slabs = torch.zeros(64, stride, device=DEV)
+    dwv, dbv, dsv = slabs[0, 0:], slabs[0, nwp:], slabs[0, nwp + 64:]
     din = torch.full((B, Cin, Lin), 0.5, device=DEV)
     pdin = torch.zeros(_lib.RAAE_MAX_PARTS, Cin, 2, dtype=torch.float64, device=DEV)
     if kind == "lenlin":
-        ops.lenlin_bwd_weight(go, B, Cin, cfg["E"], view, Lin, dw, db, ds)
+        nsl = ops.lenlin_bwd_weight(go, B, Cin, cfg["E"], view, Lin, dwv, dbv, dsv, stride)
         nd = ops.lenlin_bwd_data(go, B, Cin, cfg["E"], w, view, Lin, din, True, pdin)
     else:
-        ops.conv_bwd_weight(go, B, cv, view, dw, db, ds)
+        nsl = ops.conv_bwd_weight(go, B, cv, view, dwv, dbv, dsv, stride)
         nd = ops.conv_bwd_data(go, B, cv, w, view, din, True, pdin)
+    tot_s = slabs[:nsl].sum(0)
+    dw, db, ds = tot_s[:w.numel()].view(w.shape), tot_s[nwp:nwp + bias.numel()], tot_s[nwp + 64:nwp + 64 + Cout]
     scale = float(r["G"].abs().mean()) * (B * Lout) ** 0.5
     close(dw, m.weight.grad, 5e-4, 5e-5 * scale, "dw")
     close(db, m.bias.grad, 5e-4, 5e-5 * scale, "dbias")
@@ -490,11 +494,11 @@ def test_sum3_and_grad_materialize():
     gp[0, :, 1] = (Gn.double() * Rn.detach().double()).sum((0, 2))
     bnY = ops.make_bn(pY, nY, B * L)
     goA = ops.make_grad(dev(Gn), raw=dev(A), slope=dev(sa), bn=bnY, g_partials=gp.to(DEV), g_nparts=1, u=y)
-    dA, dsa = torch.empty(B, Cc, L, device=DEV), torch.empty(Cc, device=DEV)
-    ops.grad_materialize(goA, B, Cc, L, dA, False, dsa)
+    dA, dsl = torch.empty(B, Cc, L, device=DEV), torch.zeros(64, 64, device=DEV)
+    nsl = ops.grad_materialize(goA, B, Cc, L, dA, False, dsl, 64)
     close(dA, Ar.grad, 2e-4, 2e-5, "dA")
-    close(dsa, sar.grad, 5e-4, 1e-4, "dslope A")
+    close(dsl[:nsl, :Cc].sum(0), sar.grad, 5e-4, 1e-4, "dslope A")
     goI = ops.make_grad(dev(Gn), bn=bnY, g_partials=gp.to(DEV), g_nparts=1, u=y)
     acc = torch.ones(B, Cc, L, device=DEV)
-    ops.grad_materialize(goI, B, Cc, L, acc, True, None)
+    ops.grad_materialize(goI, B, Cc, L, acc, True, None, 0)
     close(acc, Y.grad + 1.0, 2e-4, 2e-5, "identity shortcut gradient")
