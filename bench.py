@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--ae-form", default=os.environ.get("RANKAAE_BENCH_AE_FORM", "FC"))
+    ap.add_argument("--ae-form", default=os.environ.get("RANKAAE_BENCH_AE_FORM", "compact"))
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--rows", type=int, default=7000)
     ap.add_argument("--no-graph", action="store_true")

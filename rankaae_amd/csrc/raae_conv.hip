@@ -8,6 +8,7 @@
 // BatchNorm partial sums are per-workgroup scalars (fixed order, no atomics); parameter
 // gradients are produced one workgroup per element as final values.
 #include "raae_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -485,6 +486,7 @@ int pick_S(long floats_per_sample, long outputs_per_sample, int B, long lds_budg
     if (S < 1) S = 1;
     return (int)S;
 }
+int lg2(int v) { if (v <= 0 || (v & (v - 1))) return -1; int s = 0; while ((1 << s) < v) ++s; return s; }
 const long kTileBudget = 10 * 1024;    // floats (40 KB) of dynamic LDS for staged tiles
 
 }  // namespace
@@ -501,7 +503,7 @@ extern "C" int raae_conv_fwd(const raae_view_t* in, int B, const raae_conv_t* cv
     const long per_in = (long)cv->Cin * (cv->Lin + 2 * (cv->transposed ? 0 : cv->pad));
     if (conv_nw(cv) <= 1024 && (stats_kind == RAAE_OUT_RAW || cv->Cout <= CT_MAXCH) && per_in <= kTileBudget) {
         ConvFwdTArgs t;
-        t.a = a;
+        t.a = a; t.sh_in = lg2(cv->Lin); t.sh_out = lg2(cv->Lout);
         t.S = pick_S(per_in, (long)cv->Cout * cv->Lout, B, kTileBudget, 256);
         t.ngroups = (B + t.S - 1) / t.S;
         const int grid = t.ngroups < RAAE_MAX_PARTS ? t.ngroups : RAAE_MAX_PARTS;
@@ -528,7 +530,7 @@ extern "C" int raae_conv_bwd_data(const raae_grad_t* go, int B, const raae_conv_
     const long per_g = (long)cv->Cout * cv->Lout;
     if (conv_nw(cv) <= 1024 && (!din_partials || cv->Cin <= CT_MAXCH) && per_g <= kTileBudget) {
         ConvBwdDataTArgs t;
-        t.a = a;
+        t.a = a; t.sh_in = lg2(cv->Lin); t.sh_out = lg2(cv->Lout);
         t.S = pick_S(per_g, (long)cv->Cin * cv->Lin, B, kTileBudget, 256);
         t.ngroups = (B + t.S - 1) / t.S;
         const int grid = t.ngroups < RAAE_MAX_PARTS ? t.ngroups : RAAE_MAX_PARTS;
@@ -555,7 +557,8 @@ extern "C" int raae_conv_bwd_weight(const raae_grad_t* go, int B, const raae_con
     const long per = (long)(dslope ? 2 : 1) * cv->Cout * cv->Lout + (long)cv->Cin * (cv->Lin + 2 * (cv->transposed ? 0 : cv->pad));
     if (a.nw <= 1024 && cv->Cout <= 8 && per <= kTileBudget) {
         ConvBwdWTArgs t;
-        t.a = a; t.slab_stride = slab_stride;
+        t.a = a; t.slab_stride = slab_stride; t.sh_in = lg2(cv->Lin); t.sh_out = lg2(cv->Lout);
+        { const char* d_ = getenv("RAAE_DBG"); t.dbg = d_ ? atoi(d_) : 0; }
         const long span = cv->transposed ? cv->Lin : cv->Lout;      // inner-loop trip count per sample
         t.S = pick_S(per, span, B, kTileBudget, 256);
         t.ngroups = (B + t.S - 1) / t.S;
@@ -582,8 +585,8 @@ extern "C" int raae_lenlin_fwd(const raae_view_t* in, int B, int C, int Lin, con
     const long wfl = (long)E * Lin + E, per = (long)C * Lin;
     if ((stats_kind == RAAE_OUT_RAW || C <= CT_MAXCH) && wfl <= 2048 && per <= kTileBudget - wfl) {
         LenLinFwdTArgs t;
-        t.a = a;
-        t.S = pick_S(per, (long)C * E, B, kTileBudget - wfl, Lin >= 32 ? 32 : 256);
+        t.a = a; t.sh_in = lg2(Lin); t.sh_e = lg2(E);
+        t.S = pick_S(per, (long)C * E, B, kTileBudget - wfl, Lin >= 64 ? 16 : 256);
         t.ngroups = (B + t.S - 1) / t.S;
         const int grid = t.ngroups < RAAE_MAX_PARTS ? t.ngroups : RAAE_MAX_PARTS;
         t.a.nsl = grid;
@@ -609,8 +612,8 @@ extern "C" int raae_lenlin_bwd_data(const raae_grad_t* go, int B, int C, int E, 
     const long wfl = (long)E * Lin, per = (long)C * E;
     if ((!din_partials || C <= CT_MAXCH) && wfl <= 2048 && per <= kTileBudget - wfl) {
         LenLinBwdDataTArgs t;
-        t.a = a;
-        t.S = pick_S(per, (long)C * Lin, B, kTileBudget - wfl, (E >= 32 && Lin <= 8) ? 32 : 256);
+        t.a = a; t.sh_in = lg2(Lin); t.sh_e = lg2(E);
+        t.S = pick_S(per, (long)C * Lin, B, kTileBudget - wfl, E >= 64 ? 16 : 256);
         t.ngroups = (B + t.S - 1) / t.S;
         const int grid = t.ngroups < RAAE_MAX_PARTS ? t.ngroups : RAAE_MAX_PARTS;
         t.a.nsl = grid;
@@ -635,7 +638,7 @@ extern "C" int raae_lenlin_bwd_weight(const raae_grad_t* go, int B, int C, int E
     const long per = (long)(dslope ? 2 : 1) * C * E + (long)C * Lin;
     if ((long)E * Lin <= 1024 && E <= 256 && C <= CT_MAXCH && per <= kTileBudget) {
         LenLinBwdWTArgs t;
-        t.a = a; t.slab_stride = slab_stride;
+        t.a = a; t.slab_stride = slab_stride; t.sh_in = lg2(Lin); t.sh_e = lg2(E);
         t.S = pick_S(per, C, B, kTileBudget, 64);             // >= 64 rows (s, c) per staging
         t.ngroups = (B + t.S - 1) / t.S;
         const int grid = t.ngroups < 64 ? t.ngroups : 64;

@@ -217,8 +217,9 @@ class FCNet:
                 out_kind, oslope = OUT_STATS_RAW, None
             else:
                 out_kind, oslope = (OUT_RELU if self.final_relu else OUT_SOFTPLUS), None
-            ws.nparts[i] = ops.dense_fwd(xin, b, l.K, in_kind, slope, bn, mask, l.w, l.b, l.N, ws.z[i], out_kind,
-                                         oslope, ws.part[i])
+            nbytes = 4 * (b * l.K * (2 if mask is not None else 1) + l.N * l.K + l.N + b * l.N)
+            ws.nparts[i] = eng.probe_launch("dense_fwd", nbytes, lambda: ops.dense_fwd(
+                xin, b, l.K, in_kind, slope, bn, mask, l.w, l.b, l.N, ws.z[i], out_kind, oslope, ws.part[i]))
         if self.kind == "enc":
             ops.style_bn_fwd(ws.z[-1], b, self.out_dim, self._bn_in(ws, len(L) - 1, train, True), ws.styles)
         if train:
@@ -401,6 +402,7 @@ class StepEngine:
         self.phase_hook = None
         self.post_phase_hook = None
         self._capture = None
+        self._probe = None
         n_side = int(self.cfg.get("side_streams", 3))
         self.side_streams = [torch.cuda.Stream(device=device) for _ in range(n_side)]
         self._side_i, self._side_used = 0, set()
@@ -475,6 +477,7 @@ class StepEngine:
         self.perm.copy_(torch.as_tensor(perm, dtype=torch.int64))
         self.cursor_start, self.cursor_stride = int(start), stride
         self._cursor_primed = False
+        self._host_cursor = int(start)       # host mirror of the device row cursor (bounds check)
         self.alpha_dev.fill_(float(alpha))
         self.loss_out[LOSS_SLOTS["mi_accum"]] = 0.0
 
@@ -633,9 +636,13 @@ class StepEngine:
     def step(self, b, smooth=True):
         """Run one training step on the next ``b`` rows of the epoch permutation."""
         P = self.plan(b)
+        stride = self.cursor_stride if self.cursor_stride is not None else b
+        if self._host_cursor + b > len(self.train_spec):
+            raise RuntimeError(f"epoch exhausted: rows [{self._host_cursor}, {self._host_cursor + b}) exceed the "
+                               f"{len(self.train_spec)}-row training split; call set_epoch() first")
+        self._host_cursor += stride
         if not self._cursor_primed:
             # the tick adds `stride` BEFORE the gather, which reads rows [cursor - b, cursor)
-            stride = self.cursor_stride if self.cursor_stride is not None else b
             self.cursor.fill_(self.cursor_start + b - stride)
             self._cursor_primed = True
         if self.rng_mode == "host":
@@ -668,6 +675,79 @@ class StepEngine:
             self._count_bn_step(smooth)
         else:
             self.emit_step(P, smooth, record=False)
+
+    # -- roofline probe (bench.py): HIP-event timing of every launch of the step's dominant kernel
+    def probe_launch(self, kind, nbytes, fn):
+        """Run ``fn`` (one kernel launch); when a probe for ``kind`` is armed, bracket it with HIP
+        events recorded on the stream the kernel is launched on."""
+        pr = self._probe
+        if pr is None or pr["kind"] != kind:
+            return fn()
+        e0, e1 = ops.Event(), ops.Event()
+        e0.record()
+        out = fn()
+        e1.record()
+        pr["events"].append((e0, e1, nbytes))
+        return out
+
+    @_on_stream
+    def roofline_probe(self, b, peak_gbs, reps=5):
+        """Dominant kernel of this workload (by rocprofv3 share: conv weight-gradient kernel for
+        ``compact``, fused dense forward for ``FC``): algorithmic bytes per launch / average
+        HIP-event duration, over ``reps`` eager steps; plus the same for the largest Conv1d of the
+        model run alone at batch 4096, where the launch floor no longer hides the kernel."""
+        kind = "conv_bwd_weight" if self.cfg["ae_form"] == "compact" else "dense_fwd"
+        saved_graph, saved_hooks = self.use_graph, (self.phase_hook, self.post_phase_hook)
+        self.use_graph = False
+        self.set_epoch(self.perm.clone(), float(self.alpha_dev))
+        self._probe = {"kind": kind, "events": []}
+        for _ in range(reps):
+            self.step(b, smooth=True)
+        torch.cuda.synchronize()
+        ev = self._probe["events"]
+        self._probe = None
+        self.use_graph = saved_graph
+        t_us = [1e3 * a.elapsed_ms(z) for a, z, _ in ev]
+        nbytes = [n for *_, n in ev]
+        avg_us, avg_bytes = float(np.mean(t_us)), float(np.mean(nbytes))
+        ach = avg_bytes / (avg_us * 1e-6) / 1e9
+        out = {"bound": "hbm", "kernel": {"conv_bwd_weight": "conv_bwd_weight_tiled_kernel",
+                                          "dense_fwd": "dense_fwd_kernel"}[kind],
+               "achieved": round(ach, 2), "peak": peak_gbs, "unit": "GB/s", "frac": round(ach / peak_gbs, 5),
+               "traffic": None, "launches_per_step": len(ev) // reps, "avg_launch_us": round(avg_us, 2),
+               "algorithmic_bytes_per_launch": int(avg_bytes),
+               "note": "batch 256 is launch/latency bound (SURVEY 8d): every kernel moves <= 2 MB"}
+        if self.cfg["ae_form"] == "compact":
+            out["conv1d_fwd_B4096"] = self._probe_big_conv(peak_gbs)
+        return out
+
+    def _probe_big_conv(self, peak_gbs, B=4096, reps=20):
+        """(B,4,256) -> (B,4,256), k=11, stride 1, replicate pad: the decoder's last-block conv1 with its
+        BatchNorm prologue and PReLU+statistics epilogue (SURVEY 8d's example layer), alone at B=4096."""
+        from ._lib import OUT_STATS_PRELU
+        dev = self.device
+        m = self.dec_mod.main[3]
+        x = torch.randn(B, 4, 256, device=dev)
+        part = torch.zeros(RAAE_MAX_PARTS, 4, 2, dtype=torch.float64, device=dev)
+        part[0, :, 0] = x.double().sum((0, 2))
+        part[0, :, 1] = (x.double() ** 2).sum((0, 2))
+        rm, rv = torch.zeros(4, device=dev), torch.ones(4, device=dev)
+        view = ops.make_view(x, None, ops.make_bn(part, 1, B * 256, rm, rv))
+        cv = ops.make_conv(4, 256, 4, 256, 11, 1, 5, True, 1, False)
+        out = torch.empty(B, 4, 256, device=dev)
+        po = torch.zeros(RAAE_MAX_PARTS, 4, 2, dtype=torch.float64, device=dev)
+        for _ in range(3):
+            ops.conv_fwd(view, B, cv, m.conv1.weight, m.conv1.bias, out, OUT_STATS_PRELU, m.relu1.weight, po)
+        e0, e1 = ops.Event(), ops.Event()
+        e0.record()
+        for _ in range(reps):
+            ops.conv_fwd(view, B, cv, m.conv1.weight, m.conv1.bias, out, OUT_STATS_PRELU, m.relu1.weight, po)
+        e1.record()
+        us = 1e3 * e0.elapsed_ms(e1) / reps
+        nbytes = 4 * B * (4 * 256 + 4 * 256) + 4 * (4 * 4 * 11 + 4)
+        ach = nbytes / (us * 1e-6) / 1e9
+        return {"kernel": "conv_fwd_tiled_kernel", "avg_launch_us": round(us, 2), "algorithmic_bytes": nbytes,
+                "achieved": round(ach, 1), "unit": "GB/s", "frac": round(ach / peak_gbs, 4)}
 
     def phase_gradient(self, P, name):
         """Flat gradient (fixed-order slab sum) of optimizer ``name``'s arena range -- what the

@@ -144,9 +144,11 @@ class CompactNet:
         """conv parameter gradients -> slabs; records the slab count of every tensor written."""
         eng = self.eng
         ps = [conv.weight, conv.bias] + ([prelu.weight] if prelu is not None else [])
+        nbytes = 4 * b * (cv.Cin * cv.Lin + cv.Cout * cv.Lout) + 4 * (conv.weight.numel() + conv.bias.numel())
         with eng.side_stream():
-            ns = ops.conv_bwd_weight(go, b, cv, view, eng.gslab(conv.weight), eng.gslab(conv.bias),
-                                     eng.gslab(prelu.weight) if prelu is not None else None, eng.arena.n)
+            ns = eng.probe_launch("conv_bwd_weight", nbytes, lambda: ops.conv_bwd_weight(
+                go, b, cv, view, eng.gslab(conv.weight), eng.gslab(conv.bias),
+                eng.gslab(prelu.weight) if prelu is not None else None, eng.arena.n))
         eng.note_slabs(ps, ns)
 
     def _lw(self, go, b, Cc, E, view, Lin, lin, prelu):
