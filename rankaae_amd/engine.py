@@ -548,8 +548,8 @@ class StepEngine:
             self.post_phase_hook(name, P)
 
     def _all_reduce(self, buf):
-        import torch.distributed as dist
-        dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.pg)
+        from .parallel import allreduce_mean_
+        allreduce_mean_(buf, self.pg)
 
     def _collective(self, buf):
         """Eager emission: run the all-reduce now.  Under capture: close the current graph segment,

@@ -1,0 +1,149 @@
+"""CPU tests of the host-side mirror of the reference interface (no GPU, no HIP compute):
+configuration object, dataset split / shuffle order, seed parity of the parameter containers,
+LR schedule, data-parallel sharding over gloo (world_size 2)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from rankaae_amd import model as pm
+from rankaae_amd.dataloader import get_dataloaders, split_counts
+from rankaae_amd.parameter import Parameters
+from rankaae_amd.synthetic import make_spectra, write_csv
+from rankaae_amd.trainer import PlateauScheduler, alpha
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_parameters_mirror_reference_semantics(tmp_path):
+    """Same behaviour the reference pins in sc/tests/test_parameters.py."""
+    d = dict(nstyle=2, weight_decay=1e-2, lr_ratio_Reconn=2.0, optimizer_name="AdamW", aux_weights=None,
+             kendall_activation=False)
+    p = Parameters(d)
+    assert p.get("nstyle", 0) == 2 and p.get("nstyll", 0) == 0
+    with pytest.raises(TypeError):
+        p.nstyle = 3
+    p.update({"new_parameter1": 1.2})
+    assert p.new_parameter1 == 1.2 and p.nstyle == 2
+    d.update({"nstyle": 3, "kendall_activation": True})
+    p.update(d)
+    assert p.nstyle == 3 and p.kendall_activation is True and p.to_dict()["nstyle"] == 3
+    y = tmp_path / "fix_config.yaml"
+    y.write_text("ae_form: FC\nalpha_limit: 0.7172\nn_aux: 5\n")
+    q = Parameters.from_yaml(str(y))
+    assert q.ae_form == "FC" and q.alpha_limit == 0.7172
+
+
+@pytest.mark.parametrize("case", ["fc_small", "compact_small", "fc_512_aux12"])
+def test_containers_reproduce_reference_initial_weights(case):
+    """Constructing the product's containers in the reference's order from the same seed gives the
+    reference's initial weights (checksums stored in the golden fixtures) and state_dict keys."""
+    with open(os.path.join(GOLDEN, f"ref_{case}.json")) as f:
+        g = json.load(f)
+    c = g["config"]
+    torch.manual_seed(g["model_seed"])
+    cls = pm.AE_CLS_DICT[c["ae_form"]]
+    enc = cls["encoder"](nstyle=c["nstyle"], dropout_rate=c["dropout_rate"], dim_in=c["dim_in"], n_layers=c["n_layers"])
+    dec = cls["decoder"](nstyle=c["nstyle"], dropout_rate=c["dropout_rate"], last_layer_activation=c["decoder_activation"],
+                         dim_out=c["dim_out"], n_layers=c["n_layers"])
+    dis = pm.DiscriminatorFC(nstyle=c["nstyle"], dropout_rate=c["dis_dropout_rate"], noise=c["dis_noise"],
+                             layers=c["FC_discriminator_layers"])
+    for name, mod in (("Encoder", enc), ("Decoder", dec), ("Style Discriminator", dis)):
+        want = g["init_checksum"][name]
+        sd = mod.state_dict()
+        assert list(sd.keys()) == list(want.keys())
+        for k, v in sd.items():
+            got = [float(v.double().sum()), float(v.double().abs().sum())]
+            assert np.allclose(got, want[k], rtol=1e-12, atol=1e-12), (name, k)
+
+
+def test_dataset_split_and_shuffle_order(tmp_path):
+    spec, aux, grid = make_spectra(100, 16, 5, seed=3)
+    csv = tmp_path / "d.csv"
+    write_csv(str(csv), spec, aux, grid)
+    tr, va, te = get_dataloaders(str(csv), 8, (0.7, 0.15, 0.15), n_aux=5)
+    assert [len(x.dataset) for x in (tr, va, te)] == split_counts(100) == [70, 15, 15]
+    assert len(tr) == 9                      # last, partial batch is kept (drop_last=False)
+    np.testing.assert_allclose(tr.dataset.spec, spec[:70])
+    np.testing.assert_allclose(va.dataset.aux, aux[70:85])
+    assert split_counts(700)[0] == 489       # int(700 * 0.7) as the reference computes it
+    from oracle.ref_train import epoch_permutation
+    torch.manual_seed(5)
+    a = tr.epoch_permutation()
+    torch.manual_seed(5)
+    b = epoch_permutation(70)
+    assert torch.equal(a, b)
+    torch.manual_seed(5)
+    rows = [x[0].shape[0] for x in tr]
+    assert rows == [8] * 8 + [6]
+
+
+def test_plateau_scheduler_matches_torch():
+    class Opt:
+        lr = 0.01
+
+        def push(self):
+            pass
+    mine = PlateauScheduler(Opt(), factor=0.1, patience=3)
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=0.01)
+    ref = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="min", factor=0.1, patience=3, cooldown=0, threshold=0.01)
+    rng = np.random.default_rng(0)
+    for m in np.concatenate([np.linspace(1, 0.5, 10), 0.5 + 0.001 * rng.standard_normal(30), -0.2 - 0.01 * np.arange(10)]):
+        mine.step(m)
+        ref.step(m)
+        assert abs(mine.opt.lr - opt.param_groups[0]["lr"]) < 1e-15
+
+
+def test_alpha_ramp():
+    assert alpha(0.0, 739, 0.7172) == 0.0
+    assert abs(alpha(1.0, 739, 0.7172) - 0.7172) < 1e-5
+
+
+def test_no_cpu_fallback():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from rankaae_amd.engine import StepEngine
+    with pytest.raises(RuntimeError, match="MI355X"):
+        StepEngine(None, None, None, {}, torch.device("cpu"))
+
+
+def _dp_worker(rank, world, port, out):
+    import torch.distributed as dist
+    from rankaae_amd.parallel import allreduce_mean_, cursor_params, full_global_batches, shard_rows
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    perm = torch.randperm(100, generator=torch.Generator().manual_seed(1))
+    b = 8
+    nb = full_global_batches(100, world, b)
+    start, stride = cursor_params(rank, world, b)
+    mine = [shard_rows(perm, rank, world, b, i) for i in range(nb)]
+    for i, rows in enumerate(mine):            # what the device cursor walks: perm[start + i*stride : +b]
+        assert torch.equal(rows, perm[start + i * stride:start + i * stride + b])
+    gathered = [None] * world
+    dist.all_gather_object(gathered, torch.cat(mine).tolist())
+    flat = sum(gathered, [])
+    ok_cover = sorted(flat) == sorted(perm[:nb * world * b].tolist()) and len(set(flat)) == len(flat)
+    g = torch.full((64,), float(rank + 1))
+    allreduce_mean_(g)
+    ok_mean = bool(torch.allclose(g, torch.full((64,), (world + 1) / 2.0)))
+    if rank == 0:
+        out.put((nb, ok_cover, ok_mean))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_sharding_and_gradient_mean_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    nb, ok_cover, ok_mean = out.get(timeout=10)
+    assert nb == 6 and ok_cover and ok_mean
