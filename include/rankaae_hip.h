@@ -216,6 +216,35 @@ int raae_sum3_fwd(const raae_view_t* a, const raae_view_t* b, const raae_view_t*
 int raae_grad_materialize(const raae_grad_t* go, int B, int C, int L, float* draw, int accumulate, float* dslope,
                           long slab_stride, int* nslab, void* stream);
 
+/* ---- fused residual-block forward (EncodingBlock / DecodingBlock, reference model.py:24-174) ----
+ * BatchNorm (batch statistics) is the only grid-wide dependency inside a block, so its forward is two kernels:
+ *   A: R = bn1(X) staged once per sample -> T1 = conv1(R) (+stats of PReLU1), Sh = conv_short(R),
+ *      E1 = fc1(dropout(R)), E2 = fc2(PReLU(E1)) (+stats of PReLU when pE2 != NULL)
+ *   B: T2 = conv2(bn2(PReLU1(T1))), E3 = conv_excit(bn_e(PReLU(E2))), Y = PReLU2(T2) + PReLUs(Sh)|R + PReLUe(E3|E2)
+ *      (+stats of Y).  Trailing "reserved" fields are filled by the library.  Needs Cin, Cout <= 8. */
+typedef struct {
+    raae_view_t in;            /* block input X through bn1 (has_bn = 0 if the block has none); in.mask = NULL */
+    const float* mask;         /* dropout scale of the excitation branch [B][Cin][Lin] or NULL */
+    int B;
+    int Cin, Cout, Lin, L1, Lout, E;
+    raae_conv_t cv1, cvs; int has_short;
+    const float *w1, *b1, *slope1, *ws, *bs, *wf1, *bf1, *se1, *wf2, *bf2, *se2;
+    float *T1, *Sh, *E1, *E2;
+    double *pT1, *pE2;
+    int S, ngroups, sh_lin, sh_l1, sh_lout, sh_e, halo;      /* reserved */
+} raae_block_fwd_a_t;
+typedef struct {
+    raae_view_t vT1, vE2, vR;  /* T1 via PReLU1+bn2; E2 via PReLU_e2 (+bn_excit); X via bn1 (identity shortcut only) */
+    int B, Cin, Cout, L1, Lout;
+    raae_conv_t cv2, cve; int has_short, has_excit;
+    const float *w2, *b2, *slope2, *we, *be, *se3, *Sh, *ss;
+    float *T2, *E3, *Y; double* pY;
+    int S, ngroups, sh_l1, sh_lout, halo2;                   /* reserved */
+} raae_block_fwd_b_t;
+/* *nparts receives the number of partial-sum rows written to pT1 / pE2 (A) or pY (B). */
+int raae_block_fwd_a(const raae_block_fwd_a_t* a, int* nparts, void* stream);
+int raae_block_fwd_b(const raae_block_fwd_b_t* a, int* nparts, void* stream);
+
 /* Data parallel (replaces the reference's ipyparallel trial farm, sc/cmd/train_sc.py:25-45, per the
  * north star): out[i] = fixed-order sum of the slabs of element i -- the flat gradient that is then
  * averaged across ranks with one RCCL all-reduce per phase and fed to raae_adam_step as a single slab. */

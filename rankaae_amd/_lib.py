@@ -38,6 +38,25 @@ class ConvT(C.Structure):
                                        "groups", "transposed")]
 
 
+class BlockFwdAT(C.Structure):
+    """``raae_block_fwd_a_t``"""
+    _fields_ = ([("inp", ViewT), ("mask", C.c_void_p), ("B", C.c_int)] +
+                [(n, C.c_int) for n in ("Cin", "Cout", "Lin", "L1", "Lout", "E")] +
+                [("cv1", ConvT), ("cvs", ConvT), ("has_short", C.c_int)] +
+                [(n, C.c_void_p) for n in ("w1", "b1", "slope1", "ws", "bs", "wf1", "bf1", "se1", "wf2", "bf2", "se2",
+                                           "T1", "Sh", "E1", "E2", "pT1", "pE2")] +
+                [(n, C.c_int) for n in ("S", "ngroups", "sh_lin", "sh_l1", "sh_lout", "sh_e", "halo")])
+
+
+class BlockFwdBT(C.Structure):
+    """``raae_block_fwd_b_t``"""
+    _fields_ = ([("vT1", ViewT), ("vE2", ViewT), ("vR", ViewT)] +
+                [(n, C.c_int) for n in ("B", "Cin", "Cout", "L1", "Lout")] +
+                [("cv2", ConvT), ("cve", ConvT), ("has_short", C.c_int), ("has_excit", C.c_int)] +
+                [(n, C.c_void_p) for n in ("w2", "b2", "slope2", "we", "be", "se3", "Sh", "ss", "T2", "E3", "Y", "pY")] +
+                [(n, C.c_int) for n in ("S", "ngroups", "sh_l1", "sh_lout", "halo2")])
+
+
 class HipLibraryMissing(RuntimeError):
     pass
 
@@ -77,6 +96,8 @@ SIGNATURES = {
     "raae_lenlin_bwd_weight": (_I, [_PG, _I, _I, _I, _PV, _I, _P, _P, _P, _L, _PI, _P]),
     "raae_sum3_fwd": (_I, [_PV, _PV, _PV, _I, _I, _I, _P, _P, _PI, _P]),
     "raae_grad_materialize": (_I, [_PG, _I, _I, _I, _P, _I, _P, _L, _PI, _P]),
+    "raae_block_fwd_a": (_I, [C.POINTER(BlockFwdAT), _PI, _P]),
+    "raae_block_fwd_b": (_I, [C.POINTER(BlockFwdBT), _PI, _P]),
     "raae_slab_reduce": (_I, [_P, _L, _P, _L, _P, _P]),
     "raae_step_tick": (_I, [_P, _I, C.c_uint, _P, _P, _I, _P]),
     "raae_rng_fill": (_I, [_P, _P, _P, _I, _L, C.c_ulonglong, _P, _P]),

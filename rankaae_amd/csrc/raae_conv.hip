@@ -449,6 +449,7 @@ __global__ __launch_bounds__(256) void grad_materialize_kernel(GradMatArgs a) {
 }
 
 #include "raae_conv_tiled.inc"
+#include "raae_block_fused.inc"
 
 int slices_for(long per_channel, int C) {
     long n = (per_channel + 255) / 256;
@@ -675,5 +676,49 @@ extern "C" int raae_grad_materialize(const raae_grad_t* go, int B, int C, int L,
     t.nsl = (int)n; t.slab_stride = slab_stride;
     if (nslab) *nslab = t.nsl;
     hipLaunchKernelGGL(grad_materialize_sliced_kernel, dim3(t.nsl * C), dim3(256), 0, (hipStream_t)stream, t);
+    RAAE_LAUNCH_RET();
+}
+
+extern "C" int raae_block_fwd_a(const raae_block_fwd_a_t* in, int* nparts, void* stream) {
+    RAAE_CHECK_ARG(in && in->B > 0 && in->Cin >= 1 && in->Cin <= CT_MAXCH && in->Cout >= 1 && in->Cout <= CT_MAXCH);
+    RAAE_CHECK_ARG(view_ok(&in->in, in->Cin) && !in->in.mask && conv_ok(&in->cv1) && (!in->has_short || conv_ok(&in->cvs)));
+    RAAE_CHECK_ARG(in->T1 && in->E1 && in->E2 && in->pT1 && (!in->has_short || in->Sh));
+    RAAE_CHECK_ARG(in->cv1.Cin == in->Cin && in->cv1.Cout == in->Cout && in->cv1.Lin == in->Lin && in->cv1.Lout == in->L1);
+    RAAE_CHECK_ARG(!in->has_short || (in->cvs.Lin == in->Lin && in->cvs.Lout == in->Lout && in->cvs.pad == 0));
+    raae_block_fwd_a_t a = *in;
+    a.halo = a.cv1.transposed ? 0 : a.cv1.pad;
+    const long wfl = conv_nw(&a.cv1) + (a.has_short ? conv_nw(&a.cvs) : 0) + 2L * a.E * (a.Lin > a.Lout ? a.Lin : a.Lout);
+    const long per = (long)a.Cin * (a.Lin + 2 * a.halo) + (long)a.Cin * a.E;
+    RAAE_CHECK_ARG(wfl <= 4096 && per <= kTileBudget);
+    long outs = (long)a.Cout * a.L1;
+    a.S = pick_S(per, outs, a.B, kTileBudget, 256);
+    a.ngroups = (a.B + a.S - 1) / a.S;
+    a.sh_lin = lg2(a.Lin); a.sh_l1 = lg2(a.L1); a.sh_lout = lg2(a.Lout); a.sh_e = lg2(a.E);
+    const int grid = a.ngroups < RAAE_MAX_PARTS ? a.ngroups : RAAE_MAX_PARTS;
+    if (nparts) *nparts = grid;
+    const size_t lds = sizeof(float) * ((size_t)a.S * per + conv_nw(&a.cv1) + (a.has_short ? conv_nw(&a.cvs) : 0) +
+                                        (size_t)a.E * a.Lin + (size_t)a.Lout * a.E);
+    hipLaunchKernelGGL(block_fwd_a_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+    RAAE_LAUNCH_RET();
+}
+
+extern "C" int raae_block_fwd_b(const raae_block_fwd_b_t* in, int* nparts, void* stream) {
+    RAAE_CHECK_ARG(in && in->B > 0 && in->Cin >= 1 && in->Cin <= CT_MAXCH && in->Cout >= 1 && in->Cout <= CT_MAXCH);
+    RAAE_CHECK_ARG(view_ok(&in->vT1, in->Cout) && view_ok(&in->vE2, in->Cin) && conv_ok(&in->cv2));
+    RAAE_CHECK_ARG(in->has_short ? (in->Sh && in->ss) : (view_ok(&in->vR, in->Cin) && in->Cin == in->Cout));
+    RAAE_CHECK_ARG(in->has_excit ? (conv_ok(&in->cve) && in->E3 && in->cve.K == 1) : in->Cin == in->Cout);
+    RAAE_CHECK_ARG(in->T2 && in->Y && in->pY && in->cv2.Lin == in->L1 && in->cv2.Lout == in->Lout);
+    raae_block_fwd_b_t a = *in;
+    a.halo2 = a.cv2.transposed ? 0 : a.cv2.pad;
+    RAAE_CHECK_ARG(a.cv2.transposed || !a.cv2.pad_replicate);
+    const long per = (long)a.Cout * (a.L1 + 2 * a.halo2) + (a.has_excit ? (long)a.Cin * a.Lout : 0);
+    RAAE_CHECK_ARG(per <= kTileBudget);
+    a.S = pick_S(per, (long)a.Cout * a.Lout, a.B, kTileBudget, 256);
+    a.ngroups = (a.B + a.S - 1) / a.S;
+    a.sh_l1 = lg2(a.L1); a.sh_lout = lg2(a.Lout);
+    const int grid = a.ngroups < RAAE_MAX_PARTS ? a.ngroups : RAAE_MAX_PARTS;
+    if (nparts) *nparts = grid;
+    const size_t lds = sizeof(float) * ((size_t)a.S * per + conv_nw(&a.cv2) + (a.has_excit ? conv_nw(&a.cve) : 0));
+    hipLaunchKernelGGL(block_fwd_b_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
     RAAE_LAUNCH_RET();
 }

@@ -52,6 +52,7 @@ class Block:
 class CompactNet:
     def __init__(self, module, kind, eng):
         self.module, self.kind, self.eng = module, kind, eng
+        self.fused = bool(eng.cfg.get("fused_blocks", True))
         self.blocks = []
         if kind == "enc":
             L = module.lin3.in_features * 8      # dim_in = 256: three blocks 256 -> 64 -> 16 -> 8, 4 channels
@@ -169,6 +170,22 @@ class CompactNet:
             def vR(update, mask=None, k=k, m=m, X=X, pX=pX, nX=nX):
                 bn = self._bn(m.bn1, pX, nX, b * k.Lin, train, update) if m.bn1 is not None else None
                 return ops.make_view(X, None, bn, mask)
+            fused = self.fused and k.Cin <= 8 and k.Cout <= 8
+            if fused:
+                # two kernels per block: everything that only needs bn1, then everything that needs bn2 / bn_excit
+                n1 = ops.block_fwd_a(vR(True), self._mask(masks, i, train), b, k, m, w.T1, w.Sh, w.E1, w.E2, w.pT1,
+                                     w.pE2 if k.cve is not None else None)
+                w.nT1 = w.nE2 = n1
+                v1 = ops.make_view(w.T1, m.relu1.weight, self._bn(m.bn2, w.pT1, w.nT1, b * k.L1, train, True))
+                if k.cve is not None:
+                    ve2 = ops.make_view(w.E2, m.relu_excit_2.weight,
+                                        self._bn(m.bn_excit, w.pE2, w.nE2, b * k.Lout, train, True))
+                else:
+                    ve2 = ops.make_view(w.E2, m.relu_excit_2.weight)
+                w.nY = ops.block_fwd_b(v1, ve2, vR(False) if k.cvs is None else None, b, k, m, w.Sh, w.T2, w.E3, w.Y,
+                                       w.pY)
+                X, pX, nX = w.Y, w.pY, w.nY
+                continue
             w.nT1 = ops.conv_fwd(vR(True), b, k.cv1, m.conv1.weight, m.conv1.bias, w.T1, OUT_STATS_PRELU,
                                  m.relu1.weight, w.pT1)
             v1 = ops.make_view(w.T1, m.relu1.weight, self._bn(m.bn2, w.pT1, w.nT1, b * k.L1, train, True))

@@ -286,3 +286,47 @@ def grad_materialize(go, B, Cc, L, draw, accumulate=False, dslope=None, slab_str
     check(_lib.load().raae_grad_materialize(C.byref(go), B, Cc, L, _ptr(draw), 1 if accumulate else 0, _ptr(dslope),
                                             slab_stride, C.byref(n), _stream()), "raae_grad_materialize")
     return n.value
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def block_fwd_a(view_in, mask, B, k, m, T1, Sh, E1, E2, pT1, pE2):
+    """Fused forward phase A of a residual block (``k``: nets_conv.Block, ``m``: its nn.Module)."""
+    a = _lib.BlockFwdAT()
+    a.inp, a.mask, a.B = view_in, _p(mask), B
+    a.Cin, a.Cout, a.Lin, a.L1, a.Lout, a.E = k.Cin, k.Cout, k.Lin, k.L1, k.Lout, k.E
+    a.cv1 = k.cv1
+    a.has_short = 1 if k.cvs is not None else 0
+    if k.cvs is not None:
+        a.cvs = k.cvs
+        a.ws, a.bs = _p(m.conv_short.weight), _p(m.conv_short.bias)
+    a.w1, a.b1, a.slope1 = _p(m.conv1.weight), _p(m.conv1.bias), _p(m.relu1.weight)
+    a.wf1, a.bf1, a.se1 = _p(m.fc1.weight), _p(m.fc1.bias), _p(m.relu_excit_1.weight)
+    a.wf2, a.bf2, a.se2 = _p(m.fc2.weight), _p(m.fc2.bias), _p(m.relu_excit_2.weight)
+    a.T1, a.Sh, a.E1, a.E2, a.pT1, a.pE2 = _p(T1), _p(Sh), _p(E1), _p(E2), _p(pT1), _p(pE2)
+    n = C.c_int(0)
+    check(_lib.load().raae_block_fwd_a(C.byref(a), C.byref(n), _stream()), "raae_block_fwd_a")
+    return n.value
+
+
+def block_fwd_b(vT1, vE2, vR, B, k, m, Sh, T2, E3, Y, pY):
+    a = _lib.BlockFwdBT()
+    a.vT1, a.vE2 = vT1, vE2
+    if vR is not None:
+        a.vR = vR
+    a.B, a.Cin, a.Cout, a.L1, a.Lout = B, k.Cin, k.Cout, k.L1, k.Lout
+    a.cv2 = k.cv2
+    a.has_short = 1 if k.cvs is not None else 0
+    a.has_excit = 1 if k.cve is not None else 0
+    if k.cve is not None:
+        a.cve = k.cve
+        a.we, a.be, a.se3 = _p(m.conv_excit.weight), _p(m.conv_excit.bias), _p(m.relu_excit_3.weight)
+    if k.cvs is not None:
+        a.Sh, a.ss = _p(Sh), _p(m.relu_short.weight)
+    a.w2, a.b2, a.slope2 = _p(m.conv2.weight), _p(m.conv2.bias), _p(m.relu2.weight)
+    a.T2, a.E3, a.Y, a.pY = _p(T2), _p(E3), _p(Y), _p(pY)
+    n = C.c_int(0)
+    check(_lib.load().raae_block_fwd_b(C.byref(a), C.byref(n), _stream()), "raae_block_fwd_b")
+    return n.value
