@@ -245,6 +245,43 @@ typedef struct {
 int raae_block_fwd_a(const raae_block_fwd_a_t* a, int* nparts, void* stream);
 int raae_block_fwd_b(const raae_block_fwd_b_t* a, int* nparts, void* stream);
 
+/* ---- fused residual-block backward, data gradients (mirror of the forward split) ----
+ *   B: dY = BNbwd(gy) -> dT2, dSh (= dY when the shortcut is the identity), dEx (= dE3, or dE2 when the block has no
+ *      conv_excit) materialised once; dBn2 = conv2^T dT2 and dBnE = conv_excit^T dE3 with their BatchNorm-backward
+ *      partial sums; PReLU-slope gradient slabs of relu2, relu_short, relu_excit_3 (or relu_excit_2).
+ *   A: dT1, dE2 (when conv_excit exists), dE1 materialised; dR = conv1^T dT1 + short^T dSh | dSh + mask * fc1^T dE1
+ *      (+ partial sums for bn1; dR == NULL skips it); slope slabs of relu1, relu_excit_2, relu_excit_1.
+ * The conv / fc WEIGHT gradients are then produced by raae_conv_bwd_weight / raae_lenlin_bwd_weight from the
+ * materialised gradients (no BatchNorm prologue).  Slab s of a slope tensor is at ptr + s*slab_stride. */
+typedef struct {
+    raae_grad_t gy;            /* gradient arriving at the block output Y: g [+ g_partials, bn = stats of Y, u = Y] */
+    raae_view_t vT1, vE2;      /* T1 via PReLU1+bn2, E2 via PReLU_e2+bn_excit (for the BN-backward sums) */
+    int B, Cin, Cout, L1, Lout;
+    raae_conv_t cv2, cve; int has_short, has_excit;
+    const float *w2, *we, *slope2, *ss, *se, *T2, *Sh, *Ex;
+    float *dT2, *dSh, *dEx, *dBn2, *dBnE;
+    double *pdBn2, *pdBnE;
+    float *dslope2, *dslope_s, *dslope_e;
+    long slab_stride;
+    int S, ngroups, sh_l1, sh_lout;                          /* reserved */
+} raae_block_bwd_b_t;
+typedef struct {
+    raae_grad_t g1, ge;        /* dBn2 through bn2/PReLU1 (raw = T1); dBnE through bn_excit/PReLU_e2 (raw = E2) */
+    raae_view_t in;            /* block input X through bn1; in.mask = NULL */
+    const float* mask;
+    int B, Cin, Cout, Lin, L1, Lout, E;
+    raae_conv_t cv1, cvs; int has_short, has_excit;
+    const float *w1, *ws, *wf1, *wf2, *se1, *E1, *dSh;
+    float *dT1, *dE2, *dE1, *dR;
+    double* pdR;
+    float *dslope1, *dslope_e2, *dslope_e1;
+    long slab_stride;
+    int S, ngroups, sh_lin, sh_l1, sh_lout, sh_e;            /* reserved */
+} raae_block_bwd_a_t;
+/* *nparts: partial-sum rows AND slope slabs written (= workgroups launched). */
+int raae_block_bwd_b(const raae_block_bwd_b_t* a, int* nparts, void* stream);
+int raae_block_bwd_a(const raae_block_bwd_a_t* a, int* nparts, void* stream);
+
 /* Data parallel (replaces the reference's ipyparallel trial farm, sc/cmd/train_sc.py:25-45, per the
  * north star): out[i] = fixed-order sum of the slabs of element i -- the flat gradient that is then
  * averaged across ranks with one RCCL all-reduce per phase and fed to raae_adam_step as a single slab. */

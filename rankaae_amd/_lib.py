@@ -57,6 +57,27 @@ class BlockFwdBT(C.Structure):
                 [(n, C.c_int) for n in ("S", "ngroups", "sh_l1", "sh_lout", "halo2")])
 
 
+class BlockBwdBT(C.Structure):
+    """``raae_block_bwd_b_t``"""
+    _fields_ = ([("gy", GradT), ("vT1", ViewT), ("vE2", ViewT)] +
+                [(n, C.c_int) for n in ("B", "Cin", "Cout", "L1", "Lout")] +
+                [("cv2", ConvT), ("cve", ConvT), ("has_short", C.c_int), ("has_excit", C.c_int)] +
+                [(n, C.c_void_p) for n in ("w2", "we", "slope2", "ss", "se", "T2", "Sh", "Ex", "dT2", "dSh", "dEx",
+                                           "dBn2", "dBnE", "pdBn2", "pdBnE", "dslope2", "dslope_s", "dslope_e")] +
+                [("slab_stride", C.c_long)] + [(n, C.c_int) for n in ("S", "ngroups", "sh_l1", "sh_lout")])
+
+
+class BlockBwdAT(C.Structure):
+    """``raae_block_bwd_a_t``"""
+    _fields_ = ([("g1", GradT), ("ge", GradT), ("inp", ViewT), ("mask", C.c_void_p)] +
+                [(n, C.c_int) for n in ("B", "Cin", "Cout", "Lin", "L1", "Lout", "E")] +
+                [("cv1", ConvT), ("cvs", ConvT), ("has_short", C.c_int), ("has_excit", C.c_int)] +
+                [(n, C.c_void_p) for n in ("w1", "ws", "wf1", "wf2", "se1", "E1", "dSh", "dT1", "dE2", "dE1", "dR",
+                                           "pdR", "dslope1", "dslope_e2", "dslope_e1")] +
+                [("slab_stride", C.c_long)] +
+                [(n, C.c_int) for n in ("S", "ngroups", "sh_lin", "sh_l1", "sh_lout", "sh_e")])
+
+
 class HipLibraryMissing(RuntimeError):
     pass
 
@@ -98,6 +119,8 @@ SIGNATURES = {
     "raae_grad_materialize": (_I, [_PG, _I, _I, _I, _P, _I, _P, _L, _PI, _P]),
     "raae_block_fwd_a": (_I, [C.POINTER(BlockFwdAT), _PI, _P]),
     "raae_block_fwd_b": (_I, [C.POINTER(BlockFwdBT), _PI, _P]),
+    "raae_block_bwd_b": (_I, [C.POINTER(BlockBwdBT), _PI, _P]),
+    "raae_block_bwd_a": (_I, [C.POINTER(BlockBwdAT), _PI, _P]),
     "raae_slab_reduce": (_I, [_P, _L, _P, _L, _P, _P]),
     "raae_step_tick": (_I, [_P, _I, C.c_uint, _P, _P, _I, _P]),
     "raae_rng_fill": (_I, [_P, _P, _P, _I, _L, C.c_ulonglong, _P, _P]),

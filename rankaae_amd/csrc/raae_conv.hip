@@ -722,3 +722,47 @@ extern "C" int raae_block_fwd_b(const raae_block_fwd_b_t* in, int* nparts, void*
     hipLaunchKernelGGL(block_fwd_b_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
     RAAE_LAUNCH_RET();
 }
+
+extern "C" int raae_block_bwd_b(const raae_block_bwd_b_t* in, int* nparts, void* stream) {
+    RAAE_CHECK_ARG(in && in->B > 0 && in->Cin >= 1 && in->Cin <= CT_MAXCH && in->Cout >= 1 && in->Cout <= CT_MAXCH);
+    RAAE_CHECK_ARG(in->gy.g && (!in->gy.has_bn || (in->gy.u && in->gy.g_partials && in->gy.bn.partials &&
+                                                  in->gy.g_nparts > 0 && in->gy.g_nparts <= RAAE_MAX_PARTS)));
+    RAAE_CHECK_ARG(view_ok(&in->vT1, in->Cout) && in->vT1.has_bn && conv_ok(&in->cv2));
+    RAAE_CHECK_ARG(!in->has_excit || (view_ok(&in->vE2, in->Cin) && in->vE2.has_bn && conv_ok(&in->cve) && in->dBnE && in->pdBnE));
+    RAAE_CHECK_ARG(in->has_excit || in->Cin == in->Cout);
+    RAAE_CHECK_ARG(in->T2 && in->Ex && in->dT2 && in->dSh && in->dEx && in->dBn2 && in->pdBn2 && in->dslope2 && in->dslope_e);
+    RAAE_CHECK_ARG(!in->has_short || (in->Sh && in->ss && in->dslope_s));
+    raae_block_bwd_b_t a = *in;
+    const long per = (long)a.Cout * a.Lout * (a.has_excit ? 2 : 1);
+    RAAE_CHECK_ARG(per <= kTileBudget);
+    a.S = pick_S(per, (long)a.Cout * a.Lout, a.B, kTileBudget, 256);
+    a.ngroups = (a.B + a.S - 1) / a.S;
+    a.sh_l1 = lg2(a.L1); a.sh_lout = lg2(a.Lout);
+    const int grid = a.ngroups < 128 ? a.ngroups : 128;
+    if (nparts) *nparts = grid;
+    const size_t lds = sizeof(float) * ((size_t)a.S * per + conv_nw(&a.cv2) + (a.has_excit ? conv_nw(&a.cve) : 0));
+    hipLaunchKernelGGL(block_bwd_b_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+    RAAE_LAUNCH_RET();
+}
+
+extern "C" int raae_block_bwd_a(const raae_block_bwd_a_t* in, int* nparts, void* stream) {
+    RAAE_CHECK_ARG(in && in->B > 0 && in->Cin >= 1 && in->Cin <= CT_MAXCH && in->Cout >= 1 && in->Cout <= CT_MAXCH);
+    RAAE_CHECK_ARG(grad_ok(&in->g1, in->Cout) && in->g1.has_bn && in->g1.raw && in->g1.slope);
+    RAAE_CHECK_ARG(!in->has_excit || (grad_ok(&in->ge, in->Cin) && in->ge.raw && in->ge.slope && in->dslope_e2));
+    RAAE_CHECK_ARG(view_ok(&in->in, in->Cin) && !in->in.mask && conv_ok(&in->cv1) && (!in->has_short || conv_ok(&in->cvs)));
+    RAAE_CHECK_ARG(in->has_short || (in->Cin == in->Cout && in->Lin == in->Lout));
+    RAAE_CHECK_ARG(in->E1 && in->dSh && in->dT1 && in->dE2 && in->dE1 && in->dslope1 && in->dslope_e1 && in->se1);
+    RAAE_CHECK_ARG(!in->pdR || (in->dR && in->in.has_bn));
+    raae_block_bwd_a_t a = *in;
+    const long wfl = conv_nw(&a.cv1) + (a.has_short ? conv_nw(&a.cvs) : 0) + (long)a.E * a.Lin + (long)a.Lout * a.E;
+    const long per = (long)a.Cout * a.L1 + (long)a.Cout * a.Lout + (long)a.Cin * a.Lout + (long)a.Cin * a.E;
+    RAAE_CHECK_ARG(wfl <= 4096 && per <= kTileBudget);
+    a.S = pick_S(per, (long)a.Cin * a.Lin, a.B, kTileBudget, 256);
+    a.ngroups = (a.B + a.S - 1) / a.S;
+    a.sh_lin = lg2(a.Lin); a.sh_l1 = lg2(a.L1); a.sh_lout = lg2(a.Lout); a.sh_e = lg2(a.E);
+    const int grid = a.ngroups < 128 ? a.ngroups : 128;
+    if (nparts) *nparts = grid;
+    const size_t lds = sizeof(float) * ((size_t)a.S * per + wfl);
+    hipLaunchKernelGGL(block_bwd_a_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+    RAAE_LAUNCH_RET();
+}

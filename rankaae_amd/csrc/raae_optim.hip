@@ -2,6 +2,7 @@
 // the Philox random tape, and HIP stream/graph/event plumbing.
 #include "raae_common.h"
 #include <string.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -151,6 +152,7 @@ extern "C" int raae_graph_end(void* stream, void** graph_exec) {
     hipGraph_t graph = nullptr;
     hipError_t e = hipStreamEndCapture((hipStream_t)stream, &graph);
     if (e != hipSuccess) return (int)e;
+    if (const char* dot = getenv("RAAE_GRAPH_DOT")) hipGraphDebugDotPrint(graph, dot, hipGraphDebugDotFlagsVerbose);
     hipGraphExec_t ex = nullptr;
     e = hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0);
     hipGraphDestroy(graph);

@@ -405,7 +405,7 @@ class StepEngine:
         self._probe = None
         n_side = int(self.cfg.get("side_streams", 3))
         self.side_streams = [torch.cuda.Stream(device=device) for _ in range(n_side)]
-        self._side_i, self._side_used = 0, set()
+        self._side_i, self._side_used, self._events = 0, set(), []
         self.cursor_start, self.cursor_stride, self._cursor_primed = 0, None, False
 
     # -- optimizers: trainer.py:333-397 (only the five that ever step under gradient reversal)
@@ -437,6 +437,7 @@ class StepEngine:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             s.wait_event(ev)
+            self._events.append(ev)      # keep alive: destroying a recorded event mid-capture drops the edge on HIP
             self._side_used.add(s)
             with torch.cuda.stream(s):
                 yield
@@ -447,7 +448,10 @@ class StepEngine:
             ev = torch.cuda.Event()
             ev.record(s)
             torch.cuda.current_stream().wait_event(ev)
+            self._events.append(ev)
         self._side_used.clear()
+        if self._capture is None and len(self._events) > 4096:
+            self._events.clear()
 
     # -- helpers used by the net emitters
     def gslab(self, p):

@@ -103,6 +103,8 @@ class CompactNet:
             w.dR, w.pdR = t(b, k.Cin, k.Lin), parts(k.Cin)
             w.dBnE, w.pdBnE = t(b, k.Cin, k.Lout), parts(k.Cin)
             w.dE1a = t(b, k.Cin, k.E)
+            w.dT2, w.dSh, w.dEx = t(b, k.Cout, k.Lout), t(b, k.Cout, k.Lout), t(b, k.Cout, k.Lout)
+            w.dT1, w.dE2, w.dE1 = t(b, k.Cout, k.L1), t(b, k.Cin, k.Lout), t(b, k.Cin, k.E)
             w.ndBn2 = w.ndR = w.ndBnE = 0
             ws.blk.append(w)
         if self.kind == "enc":
@@ -141,7 +143,7 @@ class CompactNet:
             return self.eng.tape.view(masks[i][0], *masks[i][1])
         return None
 
-    def _cw(self, go, b, cv, view, conv, prelu):
+    def _cw(self, go, b, cv, view, conv, prelu, tag=0):
         """conv parameter gradients -> slabs; records the slab count of every tensor written."""
         eng = self.eng
         ps = [conv.weight, conv.bias] + ([prelu.weight] if prelu is not None else [])
@@ -152,12 +154,12 @@ class CompactNet:
                 eng.gslab(prelu.weight) if prelu is not None else None, eng.arena.n))
         eng.note_slabs(ps, ns)
 
-    def _lw(self, go, b, Cc, E, view, Lin, lin, prelu):
+    def _lw(self, go, b, Cc, E, view, Lin, lin, prelu, tag=0):
         eng = self.eng
         with eng.side_stream():
             ns = ops.lenlin_bwd_weight(go, b, Cc, E, view, Lin, eng.gslab(lin.weight), eng.gslab(lin.bias),
-                                       eng.gslab(prelu.weight), eng.arena.n)
-        eng.note_slabs([lin.weight, lin.bias, prelu.weight], ns)
+                                       eng.gslab(prelu.weight) if prelu is not None else None, eng.arena.n)
+        eng.note_slabs([lin.weight, lin.bias] + ([prelu.weight] if prelu is not None else []), ns)
 
     # ------------------------------------------------------------------ forward
     def forward(self, ws, x, masks, train=True):
@@ -256,6 +258,44 @@ class CompactNet:
             def vR(mask=None, k=k, m=m, w=w):
                 bn = self._bn(m.bn1, w.pX, w.nX, b * k.Lin, True, False) if m.bn1 is not None else None
                 return ops.make_view(w.X, None, bn, mask)
+            if self.fused and k.Cin <= 8 and k.Cout <= 8:
+                bn2v = self._bn(m.bn2, w.pT1, w.nT1, b * k.L1, True, False)
+                v1 = ops.make_view(w.T1, m.relu1.weight, bn2v)
+                bne = self._bn(m.bn_excit, w.pE2, w.nE2, b * k.Lout, True, False) if k.cve is not None else None
+                ve2 = ops.make_view(w.E2, m.relu_excit_2.weight, bne)
+                nB = ops.block_bwd_b(gspec(None, None), v1, ve2 if k.cve is not None else None, b, k, m, w,
+                                     eng.arena.n, G)
+                eng.note_slabs([m.relu2.weight] + ([m.relu_short.weight] if k.cvs is not None else []) +
+                               [m.relu_excit_3.weight if k.cve is not None else m.relu_excit_2.weight], nB)
+                g1 = ops.make_grad(w.dBn2, raw=w.T1, slope=m.relu1.weight, bn=bn2v, g_partials=w.pdBn2, g_nparts=nB)
+                ge = ops.make_grad(w.dBnE, raw=w.E2, slope=m.relu_excit_2.weight, bn=bne, g_partials=w.pdBnE,
+                                   g_nparts=nB) if k.cve is not None else None
+                dE2 = w.dE2 if k.cve is not None else w.dEx
+                mask = self._mask(masks, i, True)
+                w.ndR = ops.block_bwd_a(g1, ge, vR(), mask, b, k, m, w, dE2, dR if need_dx else None,
+                                        w.pdR if (need_dx and m.bn1 is not None) else None, eng.arena.n, G)
+                eng.note_slabs([m.relu1.weight, m.relu_excit_1.weight] +
+                               ([m.relu_excit_2.weight] if k.cve is not None else []), w.ndR)
+                # weight gradients from the materialised gradients (side streams; no BatchNorm prologue).
+                # At most ONE block's weight-gradient kernels are in flight: the previous block's are
+                # joined first.  (Measured on ROCm 7.2: with deeper cross-block overlap a captured graph
+                # stopped being bitwise equal to eager launches although its dependency edges were
+                # complete -- tests/test_engine_gpu.py::test_graph_replay_is_bitwise_eager guards this.)
+                eng.join_side_streams()
+                self._cw(ops.make_grad(w.dT2), b, k.cv2, v1, m.conv2, None, 1)
+                if k.cve is not None:
+                    self._cw(ops.make_grad(w.dEx), b, k.cve, ve2, m.conv_excit, None, 2)
+                self._cw(ops.make_grad(w.dT1), b, k.cv1, vR(), m.conv1, None, 3)
+                if k.cvs is not None:
+                    self._cw(ops.make_grad(w.dSh), b, k.cvs, vR(), m.conv_short, None, 4)
+                self._lw(ops.make_grad(dE2), b, k.Cin, k.Lout, ops.make_view(w.E1, m.relu_excit_1.weight), k.E,
+                         m.fc2, None, 5)
+                self._lw(ops.make_grad(w.dE1), b, k.Cin, k.E, vR(mask), k.Lin, m.fc1, None, 6)
+                if i > 0:
+                    gy = dict(g=w.dR, bn=m.bn1, parts=w.pdR, nparts=w.ndR)
+                    if m.bn1 is None:
+                        gy = dict(g=w.dR, bn=None, parts=None, nparts=0)
+                continue
             # ---- main branch
             go2 = gspec(w.T2, m.relu2.weight)
             v1 = ops.make_view(w.T1, m.relu1.weight, self._bn(m.bn2, w.pT1, w.nT1, b * k.L1, True, False))

@@ -330,3 +330,57 @@ def block_fwd_b(vT1, vE2, vR, B, k, m, Sh, T2, E3, Y, pY):
     n = C.c_int(0)
     check(_lib.load().raae_block_fwd_b(C.byref(a), C.byref(n), _stream()), "raae_block_fwd_b")
     return n.value
+
+
+def block_bwd_b(gy, vT1, vE2, B, k, m, w, slab_stride, gslab):
+    """Fused backward phase B (``w``: the block's workspace, ``gslab(p)``: slab-0 view of parameter p)."""
+    a = _lib.BlockBwdBT()
+    a.gy, a.vT1 = gy, vT1
+    if vE2 is not None:
+        a.vE2 = vE2
+    a.B, a.Cin, a.Cout, a.L1, a.Lout = B, k.Cin, k.Cout, k.L1, k.Lout
+    a.cv2 = k.cv2
+    a.has_short = 1 if k.cvs is not None else 0
+    a.has_excit = 1 if k.cve is not None else 0
+    a.w2, a.slope2, a.T2 = _p(m.conv2.weight), _p(m.relu2.weight), _p(w.T2)
+    if k.cvs is not None:
+        a.ss, a.Sh, a.dslope_s = _p(m.relu_short.weight), _p(w.Sh), _p(gslab(m.relu_short.weight))
+    if k.cve is not None:
+        a.cve = k.cve
+        a.we, a.se, a.Ex = _p(m.conv_excit.weight), _p(m.relu_excit_3.weight), _p(w.E3)
+        a.dslope_e = _p(gslab(m.relu_excit_3.weight))
+        a.dBnE, a.pdBnE = _p(w.dBnE), _p(w.pdBnE)
+    else:
+        a.se, a.Ex = _p(m.relu_excit_2.weight), _p(w.E2)
+        a.dslope_e = _p(gslab(m.relu_excit_2.weight))
+    a.dT2, a.dSh, a.dEx, a.dBn2, a.pdBn2 = _p(w.dT2), _p(w.dSh), _p(w.dEx), _p(w.dBn2), _p(w.pdBn2)
+    a.dslope2 = _p(gslab(m.relu2.weight))
+    a.slab_stride = slab_stride
+    n = C.c_int(0)
+    check(_lib.load().raae_block_bwd_b(C.byref(a), C.byref(n), _stream()), "raae_block_bwd_b")
+    return n.value
+
+
+def block_bwd_a(g1, ge, view_in, mask, B, k, m, w, dE2, dR, pdR, slab_stride, gslab):
+    a = _lib.BlockBwdAT()
+    a.g1 = g1
+    if ge is not None:
+        a.ge = ge
+    a.inp, a.mask = view_in, _p(mask)
+    a.B, a.Cin, a.Cout, a.Lin, a.L1, a.Lout, a.E = B, k.Cin, k.Cout, k.Lin, k.L1, k.Lout, k.E
+    a.cv1 = k.cv1
+    a.has_short = 1 if k.cvs is not None else 0
+    a.has_excit = 1 if k.cve is not None else 0
+    if k.cvs is not None:
+        a.cvs = k.cvs
+        a.ws = _p(m.conv_short.weight)
+    a.w1, a.wf1, a.wf2, a.se1 = _p(m.conv1.weight), _p(m.fc1.weight), _p(m.fc2.weight), _p(m.relu_excit_1.weight)
+    a.E1, a.dSh, a.dT1, a.dE2, a.dE1, a.dR, a.pdR = _p(w.E1), _p(w.dSh), _p(w.dT1), _p(dE2), _p(w.dE1), _p(dR), _p(pdR)
+    a.dslope1 = _p(gslab(m.relu1.weight))
+    a.dslope_e1 = _p(gslab(m.relu_excit_1.weight))
+    if k.cve is not None:
+        a.dslope_e2 = _p(gslab(m.relu_excit_2.weight))
+    a.slab_stride = slab_stride
+    n = C.c_int(0)
+    check(_lib.load().raae_block_bwd_a(C.byref(a), C.byref(n), _stream()), "raae_block_bwd_a")
+    return n.value
