@@ -282,6 +282,19 @@ typedef struct {
 int raae_block_bwd_b(const raae_block_bwd_b_t* a, int* nparts, void* stream);
 int raae_block_bwd_a(const raae_block_bwd_a_t* a, int* nparts, void* stream);
 
+/* All conv / fc WEIGHT gradients of one residual block in ONE launch (up to 4 conv + 2 length-linear tasks run
+ * side by side on disjoint workgroup ranges).  Gradients must be direct (materialised by raae_block_bwd_a/b):
+ * go.has_bn = 0, go.slope = NULL.  nslab[i] receives the slab count of task i (conv tasks first, then lin). */
+typedef struct { raae_grad_t go; raae_conv_t cv; raae_view_t in; float* dw; float* dbias; } raae_wgrad_conv_t;
+typedef struct { raae_grad_t go; int C, E, Lin; raae_view_t in; float* dw; float* dbias; } raae_wgrad_lin_t;
+typedef struct {
+    int n_conv, n_lin, B;
+    long slab_stride;
+    raae_wgrad_conv_t conv[4];
+    raae_wgrad_lin_t lin[2];
+} raae_block_wgrad_t;
+int raae_block_wgrad(const raae_block_wgrad_t* a, int* nslab, void* stream);
+
 /* Data parallel (replaces the reference's ipyparallel trial farm, sc/cmd/train_sc.py:25-45, per the
  * north star): out[i] = fixed-order sum of the slabs of element i -- the flat gradient that is then
  * averaged across ranks with one RCCL all-reduce per phase and fed to raae_adam_step as a single slab. */

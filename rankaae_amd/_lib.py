@@ -78,6 +78,21 @@ class BlockBwdAT(C.Structure):
                 [(n, C.c_int) for n in ("S", "ngroups", "sh_lin", "sh_l1", "sh_lout", "sh_e")])
 
 
+class WgradConvT(C.Structure):
+    _fields_ = [("go", GradT), ("cv", ConvT), ("inp", ViewT), ("dw", C.c_void_p), ("dbias", C.c_void_p)]
+
+
+class WgradLinT(C.Structure):
+    _fields_ = [("go", GradT), ("C", C.c_int), ("E", C.c_int), ("Lin", C.c_int), ("inp", ViewT), ("dw", C.c_void_p),
+                ("dbias", C.c_void_p)]
+
+
+class BlockWgradT(C.Structure):
+    """``raae_block_wgrad_t``"""
+    _fields_ = [("n_conv", C.c_int), ("n_lin", C.c_int), ("B", C.c_int), ("slab_stride", C.c_long),
+                ("conv", WgradConvT * 4), ("lin", WgradLinT * 2)]
+
+
 class HipLibraryMissing(RuntimeError):
     pass
 
@@ -121,6 +136,7 @@ SIGNATURES = {
     "raae_block_fwd_b": (_I, [C.POINTER(BlockFwdBT), _PI, _P]),
     "raae_block_bwd_b": (_I, [C.POINTER(BlockBwdBT), _PI, _P]),
     "raae_block_bwd_a": (_I, [C.POINTER(BlockBwdAT), _PI, _P]),
+    "raae_block_wgrad": (_I, [C.POINTER(BlockWgradT), _PI, _P]),
     "raae_slab_reduce": (_I, [_P, _L, _P, _L, _P, _P]),
     "raae_step_tick": (_I, [_P, _I, C.c_uint, _P, _P, _I, _P]),
     "raae_rng_fill": (_I, [_P, _P, _P, _I, _L, C.c_ulonglong, _P, _P]),

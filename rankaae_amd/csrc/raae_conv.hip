@@ -766,3 +766,52 @@ extern "C" int raae_block_bwd_a(const raae_block_bwd_a_t* in, int* nparts, void*
     hipLaunchKernelGGL(block_bwd_a_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
     RAAE_LAUNCH_RET();
 }
+
+extern "C" int raae_block_wgrad(const raae_block_wgrad_t* in, int* nslab, void* stream) {
+    RAAE_CHECK_ARG(in && nslab && in->B > 0 && in->n_conv >= 0 && in->n_conv <= 4 && in->n_lin >= 0 && in->n_lin <= 2 &&
+                   in->n_conv + in->n_lin > 0);
+    static WgradMultiArgs m;          // large (kernarg by value); host-only scratch, filled per call
+    m.ntask = 0;
+    int total = 0;
+    size_t dyn = 0;
+    for (int i = 0; i < in->n_conv; ++i) {
+        const raae_wgrad_conv_t& c = in->conv[i];
+        const raae_conv_t* cv = &c.cv;
+        RAAE_CHECK_ARG(conv_ok(cv) && grad_ok(&c.go, cv->Cout) && !c.go.has_bn && !c.go.slope && view_ok(&c.in, cv->Cin) &&
+                       c.dw && c.dbias && cv->Cout <= 8);
+        ConvBwdWTArgs& t = m.conv[i];
+        t.a.go = c.go; t.a.B = in->B; t.a.cv = *cv; t.a.in = c.in; t.a.dw = c.dw; t.a.dbias = c.dbias; t.a.dslope = nullptr;
+        t.a.nw = conv_nw(cv);
+        const long per = (long)cv->Cout * cv->Lout + (long)cv->Cin * (cv->Lin + 2 * (cv->transposed ? 0 : cv->pad));
+        RAAE_CHECK_ARG(t.a.nw <= 1024 && per <= kTileBudget);
+        t.slab_stride = in->slab_stride; t.sh_in = lg2(cv->Lin); t.sh_out = lg2(cv->Lout); t.dbg = 0;
+        t.S = pick_S(per, cv->transposed ? cv->Lin : cv->Lout, in->B, kTileBudget, 256);
+        t.ngroups = (in->B + t.S - 1) / t.S;
+        const int grid = t.ngroups < 64 ? t.ngroups : 64;
+        m.first[m.ntask] = total; m.is_conv[m.ntask] = 1; m.idx[m.ntask] = i; nslab[m.ntask] = grid;
+        total += grid; ++m.ntask;
+        const size_t d = sizeof(float) * (size_t)t.S * per;
+        if (d > dyn) dyn = d;
+    }
+    for (int i = 0; i < in->n_lin; ++i) {
+        const raae_wgrad_lin_t& c = in->lin[i];
+        RAAE_CHECK_ARG(grad_ok(&c.go, c.C) && !c.go.has_bn && !c.go.slope && view_ok(&c.in, c.C) && c.dw && c.dbias &&
+                       c.C >= 1 && c.C <= CT_MAXCH && c.E >= 1 && c.E <= 256 && c.Lin >= 1 && (long)c.E * c.Lin <= 1024);
+        LenLinBwdWTArgs& t = m.lin[i];
+        t.a.go = c.go; t.a.B = in->B; t.a.C = c.C; t.a.E = c.E; t.a.in = c.in; t.a.Lin = c.Lin; t.a.dw = c.dw;
+        t.a.dbias = c.dbias; t.a.dslope = nullptr;
+        const long per = (long)c.C * c.E + (long)c.C * c.Lin;
+        RAAE_CHECK_ARG(per <= kTileBudget);
+        t.slab_stride = in->slab_stride; t.sh_in = lg2(c.Lin); t.sh_e = lg2(c.E);
+        t.S = pick_S(per, c.C, in->B, kTileBudget, 64);
+        t.ngroups = (in->B + t.S - 1) / t.S;
+        const int grid = t.ngroups < 64 ? t.ngroups : 64;
+        m.first[m.ntask] = total; m.is_conv[m.ntask] = 0; m.idx[m.ntask] = i; nslab[m.ntask] = grid;
+        total += grid; ++m.ntask;
+        const size_t d = sizeof(float) * (size_t)t.S * per;
+        if (d > dyn) dyn = d;
+    }
+    m.first[m.ntask] = total;
+    hipLaunchKernelGGL(wgrad_multi_kernel, dim3(total), dim3(256), dyn, (hipStream_t)stream, m);
+    RAAE_LAUNCH_RET();
+}

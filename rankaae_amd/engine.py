@@ -376,7 +376,11 @@ class StepEngine:
             self.G_flat = torch.zeros(self.arena.n, device=device)          # all-reduce buffer
             self.seg_ones = torch.ones(self.arena.n // 64, dtype=torch.uint8, device=device)
             import torch.distributed as dist
-            dist.broadcast(self.arena.P, src=0, group=self.pg)               # identical initial weights
+            self.comm_stream = torch.cuda.Stream(device=device)
+            torch.cuda.current_stream().synchronize()
+            with torch.cuda.stream(self.comm_stream):
+                dist.broadcast(self.arena.P, src=0, group=self.pg)           # identical initial weights
+            self.comm_stream.synchronize()
         from .nets_conv import CompactNet   # local import: conv emitters live in their own module
         if cfg["ae_form"] == "FC":
             self.enc, self.dec = FCNet(encoder, "enc", self), FCNet(decoder, "dec", self)
@@ -552,8 +556,19 @@ class StepEngine:
             self.post_phase_hook(name, P)
 
     def _all_reduce(self, buf):
+        """Mean over ranks on a dedicated communication stream.  RCCL's work events must never be recorded
+        on a stream that later captures a hipGraph: the process-group watchdog polls them with
+        hipEventQuery, which HIP rejects for an event last recorded on a capturing stream."""
         from .parallel import allreduce_mean_
-        allreduce_mean_(buf, self.pg)
+        cur = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self.comm_stream.wait_event(ev)
+        with torch.cuda.stream(self.comm_stream):
+            allreduce_mean_(buf, self.pg)
+            ev2 = torch.cuda.Event()
+            ev2.record(self.comm_stream)
+        cur.wait_event(ev2)
 
     def _collective(self, buf):
         """Eager emission: run the all-reduce now.  Under capture: close the current graph segment,

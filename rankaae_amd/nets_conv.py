@@ -282,15 +282,22 @@ class CompactNet:
                 # stopped being bitwise equal to eager launches although its dependency edges were
                 # complete -- tests/test_engine_gpu.py::test_graph_replay_is_bitwise_eager guards this.)
                 eng.join_side_streams()
-                self._cw(ops.make_grad(w.dT2), b, k.cv2, v1, m.conv2, None, 1)
+                G_ = eng.gslab
+                convs = [(ops.make_grad(w.dT2), k.cv2, v1, m.conv2), (ops.make_grad(w.dT1), k.cv1, vR(), m.conv1)]
                 if k.cve is not None:
-                    self._cw(ops.make_grad(w.dEx), b, k.cve, ve2, m.conv_excit, None, 2)
-                self._cw(ops.make_grad(w.dT1), b, k.cv1, vR(), m.conv1, None, 3)
+                    convs.append((ops.make_grad(w.dEx), k.cve, ve2, m.conv_excit))
                 if k.cvs is not None:
-                    self._cw(ops.make_grad(w.dSh), b, k.cvs, vR(), m.conv_short, None, 4)
-                self._lw(ops.make_grad(dE2), b, k.Cin, k.Lout, ops.make_view(w.E1, m.relu_excit_1.weight), k.E,
-                         m.fc2, None, 5)
-                self._lw(ops.make_grad(w.dE1), b, k.Cin, k.E, vR(mask), k.Lin, m.fc1, None, 6)
+                    convs.append((ops.make_grad(w.dSh), k.cvs, vR(), m.conv_short))
+                lins = [(ops.make_grad(dE2), k.Cin, k.Lout, k.E, ops.make_view(w.E1, m.relu_excit_1.weight), m.fc2),
+                        (ops.make_grad(w.dE1), k.Cin, k.E, k.Lin, vR(mask), m.fc1)]
+                with eng.side_stream():
+                    ns = ops.block_wgrad(b, [(g_, cv_, v_, G_(mod.weight), G_(mod.bias)) for g_, cv_, v_, mod in convs],
+                                         [(g_, c_, e_, l_, v_, G_(mod.weight), G_(mod.bias))
+                                          for g_, c_, e_, l_, v_, mod in lins], eng.arena.n)
+                for (_, _, _, mod), n_ in zip(convs, ns):
+                    eng.note_slabs([mod.weight, mod.bias], n_)
+                for (_, _, _, _, _, mod), n_ in zip(lins, ns[len(convs):]):
+                    eng.note_slabs([mod.weight, mod.bias], n_)
                 if i > 0:
                     gy = dict(g=w.dR, bn=m.bn1, parts=w.pdR, nparts=w.ndR)
                     if m.bn1 is None:

@@ -384,3 +384,19 @@ def block_bwd_a(g1, ge, view_in, mask, B, k, m, w, dE2, dR, pdR, slab_stride, gs
     n = C.c_int(0)
     check(_lib.load().raae_block_bwd_a(C.byref(a), C.byref(n), _stream()), "raae_block_bwd_a")
     return n.value
+
+
+def block_wgrad(B, conv_tasks, lin_tasks, slab_stride):
+    """``conv_tasks``: [(grad, conv_desc, view, dw, dbias)], ``lin_tasks``: [(grad, C, E, Lin, view, dw, dbias)].
+    One launch; returns the slab count per task (conv tasks first)."""
+    a = _lib.BlockWgradT()
+    a.n_conv, a.n_lin, a.B, a.slab_stride = len(conv_tasks), len(lin_tasks), B, slab_stride
+    for i, (go, cv, view, dw, db) in enumerate(conv_tasks):
+        a.conv[i].go, a.conv[i].cv, a.conv[i].inp = go, cv, view
+        a.conv[i].dw, a.conv[i].dbias = dw.data_ptr(), db.data_ptr()
+    for i, (go, Cc, E, Lin, view, dw, db) in enumerate(lin_tasks):
+        a.lin[i].go, a.lin[i].C, a.lin[i].E, a.lin[i].Lin, a.lin[i].inp = go, Cc, E, Lin, view
+        a.lin[i].dw, a.lin[i].dbias = dw.data_ptr(), db.data_ptr()
+    ns = (C.c_int * 6)()
+    check(_lib.load().raae_block_wgrad(C.byref(a), ns, _stream()), "raae_block_wgrad")
+    return list(ns)[:len(conv_tasks) + len(lin_tasks)]
