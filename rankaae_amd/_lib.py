@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librankaae_hip.so")
 
 RAAE_MAX_PARTS = 512
+ABI_VERSION = 2
 IN_NONE, IN_PRELU_BN_DROP, IN_PRELU_DROP = 0, 1, 2
 OUT_RAW, OUT_STATS_PRELU, OUT_STATS_RAW, OUT_SOFTPLUS, OUT_RELU = 0, 1, 2, 3, 4
 G_DIRECT, G_SOFTPLUS, G_PRELU_BN, G_PRELU, G_RELU = 0, 1, 2, 3, 4
@@ -152,6 +153,7 @@ SIGNATURES = {
     "raae_error_string": (C.c_char_p, [_I]),
     "raae_device_info": (_I, [_PI, _PI, C.c_char_p, _I]),
     "raae_abi_version": (_I, []),
+    "raae_source_digest": (C.c_char_p, []),
 }
 
 _lib = None
@@ -171,8 +173,35 @@ def load():
         fn = getattr(lib, name)     # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    if lib.raae_abi_version() != ABI_VERSION:
+        raise HipLibraryMissing(f"{LIB_PATH} has ABI version {lib.raae_abi_version()}, this binding needs "
+                                f"{ABI_VERSION}: rebuild with rankaae_amd/csrc/build.sh")
+    want = source_digest()
+    got = lib.raae_source_digest().decode()
+    if want is not None and got != want:
+        raise HipLibraryMissing(f"{LIB_PATH} is stale (built from sources {got}, tree has {want}): "
+                                "rebuild with rankaae_amd/csrc/build.sh")
     _lib = lib
     return lib
+
+
+def source_digest():
+    """sha256 prefix over the header and kernel sources, in build.sh's order; None when the sources are
+    not shipped next to the library."""
+    import glob
+    import hashlib
+    src = os.path.join(_HERE, "csrc")
+    hdr = os.path.join(_HERE, "..", "include", "rankaae_hip.h")
+    if not os.path.isdir(src) or not os.path.exists(hdr):
+        return None
+    files = [hdr]
+    for pat in ("raae_*.h", "raae_*.inc", "raae_*.hip"):
+        files += sorted(glob.glob(os.path.join(src, pat)))
+    h = hashlib.sha256()
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def check(code, what=""):

@@ -2,13 +2,19 @@
 # Build librankaae_hip.so for gfx950 (cross-compiles without a GPU).  In-tree output so it
 # travels to the GPU box with the snapshot.
 set -e
+export LC_ALL=C
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function"
+# every object depends on every header / .inc; the digest of all sources is baked into the library
+# (raae_source_digest) so that the Python loader can refuse a stale build.
+DIGEST=$(cat ../../include/rankaae_hip.h raae_*.h raae_*.inc raae_*.hip | sha256sum | cut -c1-16)
+if [ "$(cat .digest 2>/dev/null)" != "$DIGEST" ]; then rm -f raae_*.o; echo "$DIGEST" > .digest; fi
+FLAGS="$FLAGS -DRAAE_SOURCE_DIGEST=\"$DIGEST\""
 OBJS=""
 for f in raae_*.hip; do
   o="${f%.hip}.o"
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ raae_common.h -nt "$o" ] || [ ../../include/rankaae_hip.h -nt "$o" ]; then
+  if [ ! -f "$o" ]; then
     echo "hipcc $f"
     $HIPCC $FLAGS -c "$f" -o "$o" &
   fi

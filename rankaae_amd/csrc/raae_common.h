@@ -128,6 +128,95 @@ __device__ __forceinline__ void bnbwd_prologue(const double* partials, int npart
     __syncthreads();
 }
 
+// ---- several BatchNorm statistic reductions in ONE pass (one pair of barriers for all of them) ----
+// kind 0: partials {sum x, sum x^2}        -> o1 = mean,        o2 = rstd   (eval mode when partials == NULL)
+// kind 1: partials {sum g, sum g*y}        -> o1 = mean(g),     o2 = mean(g*y)
+struct StatJob {
+    const double* partials; int nparts; int C; float count; float eps; int kind;
+    float* o1; float* o2; float* rm; float* rv; float momentum; int update;
+};
+__device__ __forceinline__ StatJob stat_job_bn(const raae_bn_t& bn, int C, float* mean, float* rstd, bool update) {
+    StatJob j;
+    j.partials = bn.partials; j.nparts = bn.nparts; j.C = C; j.count = bn.count; j.eps = bn.eps; j.kind = 0;
+    j.o1 = mean; j.o2 = rstd; j.rm = bn.running_mean; j.rv = bn.running_var; j.momentum = bn.momentum;
+    j.update = (update && bn.update_running) ? 1 : 0;
+    return j;
+}
+__device__ __forceinline__ StatJob stat_job_bwd(const double* partials, int nparts, int C, float count, float* m1, float* m2) {
+    StatJob j;
+    j.partials = partials; j.nparts = nparts; j.C = C; j.count = count; j.eps = 0.f; j.kind = 1;
+    j.o1 = m1; j.o2 = m2; j.rm = nullptr; j.rv = nullptr; j.momentum = 0.f; j.update = 0;
+    return j;
+}
+__device__ __forceinline__ StatJob stat_job_none() {
+    StatJob j;
+    j.partials = nullptr; j.nparts = 0; j.C = 0; j.count = 1.f; j.eps = 0.f; j.kind = 2; j.o1 = j.o2 = j.rm = j.rv = nullptr;
+    j.momentum = 0.f; j.update = 0;
+    return j;
+}
+// All threads of a 256-thread block call it.  C <= 64 per job.
+template <int N>
+__device__ __forceinline__ void stat_jobs(const StatJob (&jobs)[N], bool is_block0) {
+    __shared__ double sscr[N][512];
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        const StatJob& jb = jobs[n];
+        if (jb.kind == 2 || jb.partials == nullptr) continue;
+        int Cp = 1;
+        while (Cp < jb.C) Cp <<= 1;
+        const int J = 256 / Cp, c = t & (Cp - 1), j = t / Cp;
+        double s = 0.0, q = 0.0;
+        if (c < jb.C) {
+            const double2* p = reinterpret_cast<const double2*>(jb.partials) + c;
+            int i = j;
+            for (; i + 3 * J < jb.nparts; i += 4 * J) {
+                const double2 v0 = p[(size_t)i * jb.C], v1 = p[(size_t)(i + J) * jb.C];
+                const double2 v2 = p[(size_t)(i + 2 * J) * jb.C], v3 = p[(size_t)(i + 3 * J) * jb.C];
+                s += v0.x; q += v0.y; s += v1.x; q += v1.y; s += v2.x; q += v2.y; s += v3.x; q += v3.y;
+            }
+            for (; i < jb.nparts; i += J) { const double2 v = p[(size_t)i * jb.C]; s += v.x; q += v.y; }
+        }
+        sscr[n][t] = s; sscr[n][256 + t] = q;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        const StatJob& jb = jobs[n];
+        if (jb.kind == 2) continue;
+        if (t < jb.C) {
+            if (jb.partials == nullptr) {          // eval mode: running statistics
+                jb.o1[t] = jb.rm[t];
+                jb.o2[t] = 1.0f / sqrtf(jb.rv[t] + jb.eps);
+            } else {
+                int Cp = 1;
+                while (Cp < jb.C) Cp <<= 1;
+                const int J = 256 / Cp;
+                double s = 0.0, q = 0.0;
+                for (int j = 0; j < J; ++j) { s += sscr[n][j * Cp + t]; q += sscr[n][256 + j * Cp + t]; }
+                const double inv = 1.0 / (double)jb.count;
+                if (jb.kind == 0) {
+                    const double mean = s * inv;
+                    double var = q * inv - mean * mean;
+                    if (var < 0.0) var = 0.0;
+                    jb.o1[t] = (float)mean;
+                    jb.o2[t] = (float)(1.0 / sqrt(var + (double)jb.eps));
+                    if (is_block0 && jb.update && jb.rm != nullptr) {
+                        const double n_ = (double)jb.count;
+                        const double unb = n_ > 1.0 ? var * n_ / (n_ - 1.0) : var;
+                        jb.rm[t] = (float)((1.0 - jb.momentum) * (double)jb.rm[t] + jb.momentum * mean);
+                        jb.rv[t] = (float)((1.0 - jb.momentum) * (double)jb.rv[t] + jb.momentum * unb);
+                    }
+                } else {
+                    jb.o1[t] = (float)(s * inv);
+                    jb.o2[t] = (float)(q * inv);
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace raae

@@ -691,6 +691,8 @@ extern "C" int raae_block_fwd_a(const raae_block_fwd_a_t* in, int* nparts, void*
     const long per = (long)a.Cin * (a.Lin + 2 * a.halo) + (long)a.Cin * a.E;
     RAAE_CHECK_ARG(wfl <= 4096 && per <= kTileBudget);
     long outs = (long)a.Cout * a.L1;
+    if ((long)a.Cout * a.Lout > outs) outs = (long)a.Cout * a.Lout;
+    if ((long)a.Cin * a.Lout > outs) outs = (long)a.Cin * a.Lout;
     a.S = pick_S(per, outs, a.B, kTileBudget, 256);
     a.ngroups = (a.B + a.S - 1) / a.S;
     a.sh_lin = lg2(a.Lin); a.sh_l1 = lg2(a.L1); a.sh_lout = lg2(a.Lout); a.sh_e = lg2(a.E);
@@ -735,10 +737,12 @@ extern "C" int raae_block_bwd_b(const raae_block_bwd_b_t* in, int* nparts, void*
     raae_block_bwd_b_t a = *in;
     const long per = (long)a.Cout * a.Lout * (a.has_excit ? 2 : 1);
     RAAE_CHECK_ARG(per <= kTileBudget);
-    a.S = pick_S(per, (long)a.Cout * a.Lout, a.B, kTileBudget, 256);
+    long widest = (long)a.Cout * a.Lout;
+    if ((long)a.Cout * a.L1 > widest) widest = (long)a.Cout * a.L1;
+    a.S = pick_S(per, widest, a.B, kTileBudget, 256);
     a.ngroups = (a.B + a.S - 1) / a.S;
     a.sh_l1 = lg2(a.L1); a.sh_lout = lg2(a.Lout);
-    const int grid = a.ngroups < 128 ? a.ngroups : 128;
+    const int grid = a.ngroups < 256 ? a.ngroups : 256;
     if (nparts) *nparts = grid;
     const size_t lds = sizeof(float) * ((size_t)a.S * per + conv_nw(&a.cv2) + (a.has_excit ? conv_nw(&a.cve) : 0));
     hipLaunchKernelGGL(block_bwd_b_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
@@ -757,10 +761,14 @@ extern "C" int raae_block_bwd_a(const raae_block_bwd_a_t* in, int* nparts, void*
     const long wfl = conv_nw(&a.cv1) + (a.has_short ? conv_nw(&a.cvs) : 0) + (long)a.E * a.Lin + (long)a.Lout * a.E;
     const long per = (long)a.Cout * a.L1 + (long)a.Cout * a.Lout + (long)a.Cin * a.Lout + (long)a.Cin * a.E;
     RAAE_CHECK_ARG(wfl <= 4096 && per <= kTileBudget);
-    a.S = pick_S(per, (long)a.Cin * a.Lin, a.B, kTileBudget, 256);
+    long widest = (long)a.Cin * a.Lin;
+    if ((long)a.Cout * a.L1 > widest) widest = (long)a.Cout * a.L1;
+    if ((long)a.Cout * a.Lout > widest) widest = (long)a.Cout * a.Lout;
+    if ((long)a.Cin * a.Lout > widest) widest = (long)a.Cin * a.Lout;
+    a.S = pick_S(per, widest, a.B, kTileBudget, 256);
     a.ngroups = (a.B + a.S - 1) / a.S;
     a.sh_lin = lg2(a.Lin); a.sh_l1 = lg2(a.L1); a.sh_lout = lg2(a.Lout); a.sh_e = lg2(a.E);
-    const int grid = a.ngroups < 128 ? a.ngroups : 128;
+    const int grid = a.ngroups < 256 ? a.ngroups : 256;
     if (nparts) *nparts = grid;
     const size_t lds = sizeof(float) * ((size_t)a.S * per + wfl);
     hipLaunchKernelGGL(block_bwd_a_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);

@@ -11,7 +11,7 @@ namespace {
 // Gradient of element i = fixed-order sum of seg_nslab[i/64] slabs; 0 slabs => parameter is
 // skipped (the reference skips params whose .grad is None, trainer.py:318-321).
 __global__ __launch_bounds__(256) void adam_kernel(float* p, float* m, float* v, const float* g_slabs, long slab_stride,
-                                                   const unsigned char* seg_nslab, long n, const double* hyper,
+                                                   const unsigned short* seg_nslab, long n, const double* hyper,
                                                    const int* step, int decoupled) {
     __shared__ float s_sc[8];
     if (threadIdx.x == 0) {
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void rng_fill_kernel(float* tape, const int* s
 }  // namespace
 
 extern "C" int raae_adam_step(float* p, float* m, float* v, const float* g_slabs, long slab_stride,
-                              const unsigned char* seg_nslab, long n, const double* hyper, const int* step,
+                              const unsigned short* seg_nslab, long n, const double* hyper, const int* step,
                               int decoupled, void* stream) {
     RAAE_CHECK_ARG(p && m && v && g_slabs && seg_nslab && hyper && step && n > 0 && (n % 64) == 0);
     long g = (n + 1023) / 1024;
@@ -193,12 +193,16 @@ extern "C" int raae_device_info(int* cu_count, int* lds_bytes, char* name, int n
     if (name && name_len > 0) { strncpy(name, prop.gcnArchName, name_len - 1); name[name_len - 1] = 0; }
     return 0;
 }
-extern "C" int raae_abi_version(void) { return 1; }
+extern "C" int raae_abi_version(void) { return RAAE_ABI_VERSION; }
+#ifndef RAAE_SOURCE_DIGEST
+#define RAAE_SOURCE_DIGEST "unknown"
+#endif
+extern "C" const char* raae_source_digest(void) { return RAAE_SOURCE_DIGEST; }
 
 // ---------------------------------------------------------------- data-parallel helper
 namespace {
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* g_slabs, long slab_stride,
-                                                          const unsigned char* seg_nslab, long n, float* out) {
+                                                          const unsigned short* seg_nslab, long n, float* out) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const int ns = seg_nslab[i >> 6];
         float g = 0.f;
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* g_slabs, 
 }
 }  // namespace
 
-extern "C" int raae_slab_reduce(const float* g_slabs, long slab_stride, const unsigned char* seg_nslab, long n,
+extern "C" int raae_slab_reduce(const float* g_slabs, long slab_stride, const unsigned short* seg_nslab, long n,
                                 float* out, void* stream) {
     RAAE_CHECK_ARG(g_slabs && seg_nslab && out && n > 0 && (n % 64) == 0);
     long g = (n + 1023) / 1024;

@@ -370,11 +370,11 @@ class StepEngine:
         self.rng_mode, self.seed, self.use_graph = rng_mode, int(seed), use_graph
         self.enc_mod, self.dec_mod, self.dis_mod = encoder, decoder, discriminator
         self.arena = Arena([("disc", discriminator), ("enc", encoder), ("dec", decoder)], device)
-        self.max_slab = 256
+        self.max_slab = 512
         self.G = torch.zeros(self.max_slab, self.arena.n, device=device)
         if self.world_size > 1:
             self.G_flat = torch.zeros(self.arena.n, device=device)          # all-reduce buffer
-            self.seg_ones = torch.ones(self.arena.n // 64, dtype=torch.uint8, device=device)
+            self.seg_ones = torch.ones(self.arena.n // 64, dtype=torch.int16, device=device)
             import torch.distributed as dist
             self.comm_stream = torch.cuda.Stream(device=device)
             torch.cuda.current_stream().synchronize()
@@ -529,7 +529,7 @@ class StepEngine:
         P.dspec = torch.empty(b, self.L, device=dev)
         P.dout = torch.empty(b, self.L, device=dev)
         P.lpart = torch.zeros(RAAE_MAX_PARTS, dtype=torch.float64, device=dev)
-        P.seg = {n: torch.zeros(self.arena.n // 64, dtype=torch.uint8, device=dev) for n in OPT_NAMES}
+        P.seg = {n: torch.zeros(self.arena.n // 64, dtype=torch.int16, device=dev) for n in OPT_NAMES}
         P.graphs = {}
         self.plans[b] = P
         return P
@@ -584,7 +584,7 @@ class StepEngine:
             self._capture["cur"] = g
 
     def _begin_phase(self, record):
-        self._slab_notes = np.zeros(self.arena.n // 64, dtype=np.uint8) if record else None
+        self._slab_notes = np.zeros(self.arena.n // 64, dtype=np.int16) if record else None
 
     def emit_step(self, P, smooth, record):
         """``record``: first (eager) emission -- slab counts are recorded into the Adam segment

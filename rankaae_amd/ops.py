@@ -131,12 +131,12 @@ def gather_batch(spec, aux, idx, cursor, noise, spec_noise, B, L, n_aux, spec_ou
 
 def adam_step(p, m, v, g_slabs, slab_stride, seg_nslab, n, hyper, step, decoupled):
     check(_lib.load().raae_adam_step(_ptr(p), _ptr(m), _ptr(v), _ptr(g_slabs), slab_stride,
-                                     _ptr(seg_nslab, torch.uint8), n, _ptr(hyper, torch.float64),
+                                     _ptr(seg_nslab, torch.int16), n, _ptr(hyper, torch.float64),
                                      _ptr(step, torch.int32), 1 if decoupled else 0, _stream()), "raae_adam_step")
 
 
 def slab_reduce(g_slabs, slab_stride, seg_nslab, n, out):
-    check(_lib.load().raae_slab_reduce(_ptr(g_slabs), slab_stride, _ptr(seg_nslab, torch.uint8), n, _ptr(out),
+    check(_lib.load().raae_slab_reduce(_ptr(g_slabs), slab_stride, _ptr(seg_nslab, torch.int16), n, _ptr(out),
                                        _stream()), "raae_slab_reduce")
 
 

@@ -284,7 +284,7 @@ def test_adam_matches_torch(decoupled, wd):
     rngc = torch.zeros(1, dtype=torch.int64, device=DEV)
     cursor = torch.zeros(1, dtype=torch.int32, device=DEV)
     nslab = 3
-    seg = torch.full((n // 64,), nslab, dtype=torch.uint8, device=DEV)
+    seg = torch.full((n // 64,), nslab, dtype=torch.int16, device=DEV)
     seg[5] = 0          # one segment "without gradient": must be left untouched
     for it in range(5):
         slabs = torch.randn(nslab, n, generator=g) * (0.0 if it == 3 else 1.0)     # one all-zero gradient step
