@@ -5,7 +5,7 @@ set -e
 export LC_ALL=C
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function $RAAE_EXTRA_FLAGS"
 # every object depends on every header / .inc; the digest of all sources is baked into the library
 # (raae_source_digest) so that the Python loader can refuse a stale build.
 DIGEST=$(cat ../../include/rankaae_hip.h raae_*.h raae_*.inc raae_*.hip | sha256sum | cut -c1-16)

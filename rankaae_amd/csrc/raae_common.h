@@ -11,6 +11,9 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef RAAE_STAMPS
+extern __device__ long long d_stamps[4][3][16];
+#endif
 namespace raae {
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -154,64 +157,78 @@ __device__ __forceinline__ StatJob stat_job_none() {
     j.momentum = 0.f; j.update = 0;
     return j;
 }
-// All threads of a 256-thread block call it.  C <= 64 per job.
-template <int N>
+// All threads of a 256-thread block call it.  C <= MAXC <= 64 per job.
+//   1. every job's first four partial rows per thread are requested before any is consumed (one memory
+//      round trip for all jobs together), rows beyond 4*J follow in a plain loop;
+//   2. lanes of a wave that share a channel are summed with xor-shuffles (fixed tree), the four wave
+//      results meet in LDS, and wave (n & 3) finishes job n -- two barriers in all, no serial J-loop.
+template <int N, int MAXC = 64>
 __device__ __forceinline__ void stat_jobs(const StatJob (&jobs)[N], bool is_block0) {
-    __shared__ double sscr[N][512];
-    const int t = threadIdx.x;
+    __shared__ double sw[N][2][4][MAXC];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    double2 v[N][4];
+    int cps[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        const StatJob& jb = jobs[n];
+        int cp = 1;
+        while (cp < jb.C) cp <<= 1;
+        cps[n] = cp;
+        const int J = 256 / cp, c = t & (cp - 1), j = t / cp;
+        const bool on = jb.kind != 2 && jb.partials != nullptr && c < jb.C;
+        const double2* p = reinterpret_cast<const double2*>(jb.partials) + c;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = j + u * J;
+            v[n][u] = (on && i < jb.nparts) ? p[(size_t)i * jb.C] : make_double2(0.0, 0.0);
+        }
+    }
 #pragma unroll
     for (int n = 0; n < N; ++n) {
         const StatJob& jb = jobs[n];
         if (jb.kind == 2 || jb.partials == nullptr) continue;
-        int Cp = 1;
-        while (Cp < jb.C) Cp <<= 1;
-        const int J = 256 / Cp, c = t & (Cp - 1), j = t / Cp;
-        double s = 0.0, q = 0.0;
+        const int cp = cps[n], J = 256 / cp, c = t & (cp - 1), j = t / cp;
+        double s = v[n][0].x, q = v[n][0].y;
+        s += v[n][1].x; q += v[n][1].y; s += v[n][2].x; q += v[n][2].y; s += v[n][3].x; q += v[n][3].y;
         if (c < jb.C) {
             const double2* p = reinterpret_cast<const double2*>(jb.partials) + c;
-            int i = j;
-            for (; i + 3 * J < jb.nparts; i += 4 * J) {
-                const double2 v0 = p[(size_t)i * jb.C], v1 = p[(size_t)(i + J) * jb.C];
-                const double2 v2 = p[(size_t)(i + 2 * J) * jb.C], v3 = p[(size_t)(i + 3 * J) * jb.C];
-                s += v0.x; q += v0.y; s += v1.x; q += v1.y; s += v2.x; q += v2.y; s += v3.x; q += v3.y;
-            }
-            for (; i < jb.nparts; i += J) { const double2 v = p[(size_t)i * jb.C]; s += v.x; q += v.y; }
+            for (int i = j + 4 * J; i < jb.nparts; i += J) { const double2 w = p[(size_t)i * jb.C]; s += w.x; q += w.y; }
         }
-        sscr[n][t] = s; sscr[n][256 + t] = q;
+        for (int o = 32; o >= cp; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+        if (lane < cp && lane < MAXC) { sw[n][0][wave][lane] = s; sw[n][1][wave][lane] = q; }
     }
     __syncthreads();
 #pragma unroll
     for (int n = 0; n < N; ++n) {
         const StatJob& jb = jobs[n];
-        if (jb.kind == 2) continue;
-        if (t < jb.C) {
-            if (jb.partials == nullptr) {          // eval mode: running statistics
-                jb.o1[t] = jb.rm[t];
-                jb.o2[t] = 1.0f / sqrtf(jb.rv[t] + jb.eps);
-            } else {
-                int Cp = 1;
-                while (Cp < jb.C) Cp <<= 1;
-                const int J = 256 / Cp;
-                double s = 0.0, q = 0.0;
-                for (int j = 0; j < J; ++j) { s += sscr[n][j * Cp + t]; q += sscr[n][256 + j * Cp + t]; }
-                const double inv = 1.0 / (double)jb.count;
-                if (jb.kind == 0) {
-                    const double mean = s * inv;
-                    double var = q * inv - mean * mean;
-                    if (var < 0.0) var = 0.0;
-                    jb.o1[t] = (float)mean;
-                    jb.o2[t] = (float)(1.0 / sqrt(var + (double)jb.eps));
-                    if (is_block0 && jb.update && jb.rm != nullptr) {
-                        const double n_ = (double)jb.count;
-                        const double unb = n_ > 1.0 ? var * n_ / (n_ - 1.0) : var;
-                        jb.rm[t] = (float)((1.0 - jb.momentum) * (double)jb.rm[t] + jb.momentum * mean);
-                        jb.rv[t] = (float)((1.0 - jb.momentum) * (double)jb.rv[t] + jb.momentum * unb);
-                    }
-                } else {
-                    jb.o1[t] = (float)(s * inv);
-                    jb.o2[t] = (float)(q * inv);
-                }
+        if (jb.kind == 2 || wave != (n & 3) || lane >= jb.C) continue;
+        if (jb.partials == nullptr) {              // eval mode: running statistics
+            jb.o1[lane] = jb.rm[lane];
+            jb.o2[lane] = 1.0f / sqrtf(jb.rv[lane] + jb.eps);
+            continue;
+        }
+        double s = sw[n][0][0][lane], q = sw[n][1][0][lane];
+        s += sw[n][0][1][lane]; q += sw[n][1][1][lane];
+        s += sw[n][0][2][lane]; q += sw[n][1][2][lane];
+        s += sw[n][0][3][lane]; q += sw[n][1][3][lane];
+        const double inv = 1.0 / (double)jb.count;
+        if (jb.kind == 0) {
+            const double mean = s * inv;
+            double var = q * inv - mean * mean;
+            if (var < 0.0) var = 0.0;
+            jb.o1[lane] = (float)mean;
+            // double like ATen's CPU accumulate type: a float rstd moves PReLU-slope gradients of the
+            // compact fixture by 2% (ill-conditioned sums), see DESIGN.md
+            jb.o2[lane] = (float)(1.0 / sqrt(var + (double)jb.eps));
+            if (is_block0 && jb.update && jb.rm != nullptr) {
+                const double n_ = (double)jb.count;
+                const double unb = n_ > 1.0 ? var * n_ / (n_ - 1.0) : var;
+                jb.rm[lane] = (float)((1.0 - jb.momentum) * (double)jb.rm[lane] + jb.momentum * mean);
+                jb.rv[lane] = (float)((1.0 - jb.momentum) * (double)jb.rv[lane] + jb.momentum * unb);
             }
+        } else {
+            jb.o1[lane] = (float)(s * inv);
+            jb.o2[lane] = (float)(q * inv);
         }
     }
     __syncthreads();

@@ -7,6 +7,9 @@
 // Mapping: a workgroup owns ONE channel and a contiguous slice of the (b, l) index space, so
 // BatchNorm partial sums are per-workgroup scalars (fixed order, no atomics); parameter
 // gradients are produced one workgroup per element as final values.
+#ifdef RAAE_STAMPS
+__device__ long long d_stamps[4][3][16];
+#endif
 #include "raae_common.h"
 #include <stdlib.h>
 
@@ -19,14 +22,28 @@ using raae::prelu;
 struct ViewStats { float mean[CV_MAXC]; float rstd[CV_MAXC]; };
 struct GradStats { float mean[CV_MAXC]; float rstd[CV_MAXC]; float m1[CV_MAXC]; float m2[CV_MAXC]; };
 
+// All conv kernels run 256-thread blocks with <= CV_MAXC channels: the merged statistic pass applies.
+__device__ __forceinline__ raae::StatJob view_job(const raae_view_t& v, int C, ViewStats* st, bool update) {
+    return v.has_bn ? raae::stat_job_bn(v.bn, C, st->mean, st->rstd, update) : raae::stat_job_none();
+}
 __device__ __forceinline__ void view_prologue(const raae_view_t& v, int C, ViewStats* st, bool block0) {
-    if (v.has_bn) raae::bn_prologue(v.bn, C, st->mean, st->rstd, block0);
+    const raae::StatJob jobs[1] = {view_job(v, C, st, true)};
+    raae::stat_jobs<1, CV_MAXC>(jobs, block0);
 }
 __device__ __forceinline__ void grad_prologue(const raae_grad_t& g, int C, GradStats* st) {
-    if (g.has_bn) {
-        raae::bn_prologue(g.bn, C, st->mean, st->rstd, false);
-        raae::bnbwd_prologue(g.g_partials, g.g_nparts, C, g.bn.count, st->m1, st->m2);
-    }
+    const raae::StatJob jobs[2] = {
+        g.has_bn ? raae::stat_job_bn(g.bn, C, st->mean, st->rstd, false) : raae::stat_job_none(),
+        g.has_bn ? raae::stat_job_bwd(g.g_partials, g.g_nparts, C, g.bn.count, st->m1, st->m2) : raae::stat_job_none()};
+    raae::stat_jobs<2, CV_MAXC>(jobs, false);
+}
+// statistics of a view and of a gradient in one pass
+__device__ __forceinline__ void view_grad_prologue(const raae_view_t& v, int Cv, ViewStats* vs, const raae_grad_t& g,
+                                                   int Cg, GradStats* gs) {
+    const raae::StatJob jobs[3] = {
+        view_job(v, Cv, vs, false),
+        g.has_bn ? raae::stat_job_bn(g.bn, Cg, gs->mean, gs->rstd, false) : raae::stat_job_none(),
+        g.has_bn ? raae::stat_job_bwd(g.g_partials, g.g_nparts, Cg, g.bn.count, gs->m1, gs->m2) : raae::stat_job_none()};
+    raae::stat_jobs<3, CV_MAXC>(jobs, false);
 }
 
 // value of a view at flat element idx of channel c
@@ -152,8 +169,7 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(ConvBwdDataArgs a) {
     const int ci = blockIdx.x % cv.Cin, sl = blockIdx.x / cv.Cin;
     const int cig = cv.Cin / cv.groups, cog = cv.Cout / cv.groups;
     const int grp = ci / cig, cil = ci - grp * cig;
-    view_prologue(a.in, cv.Cin, &vs, false);
-    grad_prologue(a.go, cv.Cout, &gs);
+    view_grad_prologue(a.in, cv.Cin, &vs, a.go, cv.Cout, &gs);
     for (int i = threadIdx.x; i < cog * cv.K; i += 256) {
         const int col = i / cv.K, t = i - col * cv.K;
         s_w[i] = cv.transposed ? a.w[((size_t)ci * cog + col) * cv.K + t]
@@ -221,8 +237,7 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(ConvBwdWArgs a) {
     __shared__ double shd[16];
     const raae_conv_t& cv = a.cv;
     const int cig = cv.Cin / cv.groups, cog = cv.Cout / cv.groups;
-    view_prologue(a.in, cv.Cin, &vs, false);
-    grad_prologue(a.go, cv.Cout, &gs);
+    view_grad_prologue(a.in, cv.Cin, &vs, a.go, cv.Cout, &gs);
     const int e = blockIdx.x;
     double acc = 0.0;
     if (e < a.nw) {
@@ -319,8 +334,7 @@ __global__ __launch_bounds__(256) void lenlin_bwd_data_kernel(LenLinBwdDataArgs 
     __shared__ GradStats gs;
     __shared__ double shd[16];
     const int c = blockIdx.x % a.C, sl = blockIdx.x / a.C;
-    view_prologue(a.in, a.C, &vs, false);
-    grad_prologue(a.go, a.C, &gs);
+    view_grad_prologue(a.in, a.C, &vs, a.go, a.C, &gs);
     long lo, hi;
     slice_range((long)a.B * a.Lin, a.nsl, sl, &lo, &hi);
     double s_acc = 0.0, q_acc = 0.0;
@@ -358,8 +372,7 @@ __global__ __launch_bounds__(256) void lenlin_bwd_weight_kernel(LenLinBwdWArgs a
     __shared__ ViewStats vs;
     __shared__ GradStats gs;
     __shared__ double shd[16];
-    view_prologue(a.in, a.C, &vs, false);
-    grad_prologue(a.go, a.C, &gs);
+    view_grad_prologue(a.in, a.C, &vs, a.go, a.C, &gs);
     const int x = blockIdx.x, nw = a.E * a.Lin;
     double acc = 0.0;
     if (x < nw) {
@@ -559,7 +572,6 @@ extern "C" int raae_conv_bwd_weight(const raae_grad_t* go, int B, const raae_con
     if (a.nw <= 1024 && cv->Cout <= 8 && per <= kTileBudget) {
         ConvBwdWTArgs t;
         t.a = a; t.slab_stride = slab_stride; t.sh_in = lg2(cv->Lin); t.sh_out = lg2(cv->Lout);
-        { const char* d_ = getenv("RAAE_DBG"); t.dbg = d_ ? atoi(d_) : 0; }
         const long span = cv->transposed ? cv->Lin : cv->Lout;      // inner-loop trip count per sample
         t.S = pick_S(per, span, B, kTileBudget, 256);
         t.ngroups = (B + t.S - 1) / t.S;
@@ -792,7 +804,7 @@ extern "C" int raae_block_wgrad(const raae_block_wgrad_t* in, int* nslab, void* 
         t.a.nw = conv_nw(cv);
         const long per = (long)cv->Cout * cv->Lout + (long)cv->Cin * (cv->Lin + 2 * (cv->transposed ? 0 : cv->pad));
         RAAE_CHECK_ARG(t.a.nw <= 1024 && per <= kTileBudget);
-        t.slab_stride = in->slab_stride; t.sh_in = lg2(cv->Lin); t.sh_out = lg2(cv->Lout); t.dbg = 0;
+        t.slab_stride = in->slab_stride; t.sh_in = lg2(cv->Lin); t.sh_out = lg2(cv->Lout);
         t.S = pick_S(per, cv->transposed ? cv->Lin : cv->Lout, in->B, kTileBudget, 256);
         t.ngroups = (in->B + t.S - 1) / t.S;
         const int grid = t.ngroups < 64 ? t.ngroups : 64;

@@ -1,0 +1,31 @@
+"""debug: per-stage timestamps of block 0 (needs a -DRAAE_STAMPS build)."""
+import ctypes, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+from rankaae_amd.engine import StepEngine
+from rankaae_amd.synthetic import make_spectra
+from rankaae_amd import _lib
+cfg = dict(bench.BASE_CFG); cfg.update(ae_form="compact", batch_size=256)
+spec, aux, _ = make_spectra(7000, 256, cfg["n_aux"], seed=0)
+enc, dec, dis = bench.build_models(cfg, 1234)
+dev = torch.device("cuda:0")
+eng = StepEngine(enc, dec, dis, cfg, dev, rng_mode="philox", seed=1, use_graph=True)
+eng.set_data(spec[:4900], aux[:4900])
+eng.set_epoch(torch.randperm(4900), 0.7, start=0, stride=256)
+for _ in range(6):
+    eng.step(256, smooth=True)
+torch.cuda.synchronize()
+lib = _lib.load()
+lib.raae_debug_stamps.restype = ctypes.c_int
+out = np.zeros((4, 3, 16), dtype=np.int64)
+assert lib.raae_debug_stamps(out.ctypes.data_as(ctypes.c_void_p)) == 0
+names = sys.argv[1:] if len(sys.argv) > 1 else None
+for k in range(4):
+    for g in range(3):
+        st = out[k, g]
+        idx = [i for i in range(16) if st[i] != 0]
+        if not idx:
+            continue
+        base = st[idx[0]]
+        print(f"kernel {k} gridclass {g}: " + " ".join(f"[{i}]{(st[i]-base)*0.01:.2f}" for i in idx))
