@@ -131,6 +131,21 @@ __device__ __forceinline__ void bnbwd_prologue(const double* partials, int npart
     __syncthreads();
 }
 
+
+// Copy the kernel's by-value argument struct (first and only parameter, offset 0 of the kernarg segment)
+// into LDS with ONE coalesced vector load per thread.  Scalar s_loads of a 600-byte struct come out as a
+// chain of dependent cache-line misses (the kernarg buffer is fresh for every launch): several
+// microseconds at the head of a kernel that runs for ten.  All threads call it; ends with a barrier.
+template <typename T>
+__device__ __forceinline__ const T& args_to_lds(T* slot) {
+    typedef __attribute__((address_space(4))) const unsigned* kptr_t;
+    const kptr_t kp = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned* dst = reinterpret_cast<unsigned*>(slot);
+    for (int i = threadIdx.x; i < (int)(sizeof(T) / 4); i += blockDim.x) dst[i] = kp[i];
+    __syncthreads();
+    return *slot;
+}
+
 // ---- several BatchNorm statistic reductions in ONE pass (one pair of barriers for all of them) ----
 // kind 0: partials {sum x, sum x^2}        -> o1 = mean,        o2 = rstd   (eval mode when partials == NULL)
 // kind 1: partials {sum g, sum g*y}        -> o1 = mean(g),     o2 = mean(g*y)
@@ -157,78 +172,71 @@ __device__ __forceinline__ StatJob stat_job_none() {
     j.momentum = 0.f; j.update = 0;
     return j;
 }
-// All threads of a 256-thread block call it.  C <= MAXC <= 64 per job.
-//   1. every job's first four partial rows per thread are requested before any is consumed (one memory
-//      round trip for all jobs together), rows beyond 4*J follow in a plain loop;
-//   2. lanes of a wave that share a channel are summed with xor-shuffles (fixed tree), the four wave
-//      results meet in LDS, and wave (n & 3) finishes job n -- two barriers in all, no serial J-loop.
+// All threads of a 256-thread block call it.  C <= 64 per job.
+// One WAVE per job (the k-th active job runs on wave k & 3): its 64 lanes sweep the partial rows eight
+// loads deep, lanes that share a channel meet in an xor-shuffle tree, and lanes < C finish the statistic.
+// Jobs proceed side by side on the four SIMDs; nothing goes through LDS and there is one barrier.
+// (Measured on MI355X: the loads return in 0.2 us -- what costs is dependent shuffle chains and issue
+// slots, so they are spread over waves instead of repeated in each.)
 template <int N, int MAXC = 64>
 __device__ __forceinline__ void stat_jobs(const StatJob (&jobs)[N], bool is_block0) {
-    __shared__ double sw[N][2][4][MAXC];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    double2 v[N][4];
-    int cps[N];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int rank = 0;
 #pragma unroll
     for (int n = 0; n < N; ++n) {
         const StatJob& jb = jobs[n];
-        int cp = 1;
-        while (cp < jb.C) cp <<= 1;
-        cps[n] = cp;
-        const int J = 256 / cp, c = t & (cp - 1), j = t / cp;
-        const bool on = jb.kind != 2 && jb.partials != nullptr && c < jb.C;
-        const double2* p = reinterpret_cast<const double2*>(jb.partials) + c;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = j + u * J;
-            v[n][u] = (on && i < jb.nparts) ? p[(size_t)i * jb.C] : make_double2(0.0, 0.0);
-        }
-    }
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-        const StatJob& jb = jobs[n];
-        if (jb.kind == 2 || jb.partials == nullptr) continue;
-        const int cp = cps[n], J = 256 / cp, c = t & (cp - 1), j = t / cp;
-        double s = v[n][0].x, q = v[n][0].y;
-        s += v[n][1].x; q += v[n][1].y; s += v[n][2].x; q += v[n][2].y; s += v[n][3].x; q += v[n][3].y;
-        if (c < jb.C) {
-            const double2* p = reinterpret_cast<const double2*>(jb.partials) + c;
-            for (int i = j + 4 * J; i < jb.nparts; i += J) { const double2 w = p[(size_t)i * jb.C]; s += w.x; q += w.y; }
-        }
-        for (int o = 32; o >= cp; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-        if (lane < cp && lane < MAXC) { sw[n][0][wave][lane] = s; sw[n][1][wave][lane] = q; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-        const StatJob& jb = jobs[n];
-        if (jb.kind == 2 || wave != (n & 3) || lane >= jb.C) continue;
+        if (jb.kind == 2) continue;
+        const bool mine = (rank & 3) == wave;
+        ++rank;
+        if (!mine) continue;
         if (jb.partials == nullptr) {              // eval mode: running statistics
-            jb.o1[lane] = jb.rm[lane];
-            jb.o2[lane] = 1.0f / sqrtf(jb.rv[lane] + jb.eps);
+            if (lane < jb.C) {
+                jb.o1[lane] = jb.rm[lane];
+                jb.o2[lane] = 1.0f / sqrtf(jb.rv[lane] + jb.eps);
+            }
             continue;
         }
-        double s = sw[n][0][0][lane], q = sw[n][1][0][lane];
-        s += sw[n][0][1][lane]; q += sw[n][1][1][lane];
-        s += sw[n][0][2][lane]; q += sw[n][1][2][lane];
-        s += sw[n][0][3][lane]; q += sw[n][1][3][lane];
-        const double inv = 1.0 / (double)jb.count;
-        if (jb.kind == 0) {
-            const double mean = s * inv;
-            double var = q * inv - mean * mean;
-            if (var < 0.0) var = 0.0;
-            jb.o1[lane] = (float)mean;
-            // double like ATen's CPU accumulate type: a float rstd moves PReLU-slope gradients of the
-            // compact fixture by 2% (ill-conditioned sums), see DESIGN.md
-            jb.o2[lane] = (float)(1.0 / sqrt(var + (double)jb.eps));
-            if (is_block0 && jb.update && jb.rm != nullptr) {
-                const double n_ = (double)jb.count;
-                const double unb = n_ > 1.0 ? var * n_ / (n_ - 1.0) : var;
-                jb.rm[lane] = (float)((1.0 - jb.momentum) * (double)jb.rm[lane] + jb.momentum * mean);
-                jb.rv[lane] = (float)((1.0 - jb.momentum) * (double)jb.rv[lane] + jb.momentum * unb);
+        int cp = 1;
+        while (cp < jb.C) cp <<= 1;
+        const int J = 64 / cp, c = lane & (cp - 1), j = lane / cp;
+        const double2* p = reinterpret_cast<const double2*>(jb.partials) + (c < jb.C ? c : 0);
+        const int last = jb.nparts - 1;
+        double s = 0.0, q = 0.0;
+        for (int i = j; i < jb.nparts; i += 8 * J) {
+            double2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {          // clamped address, value dropped below: no branch per load
+                const int r = i + u * J;
+                v[u] = p[(size_t)(r < last ? r : last) * jb.C];
             }
-        } else {
-            jb.o1[lane] = (float)(s * inv);
-            jb.o2[lane] = (float)(q * inv);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool ok = i + u * J <= last;
+                s += ok ? v[u].x : 0.0; q += ok ? v[u].y : 0.0;
+            }
+        }
+        if (c >= jb.C) { s = 0.0; q = 0.0; }
+        for (int o = 32; o >= cp; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+        if (lane < jb.C) {
+            const double inv = 1.0 / (double)jb.count;
+            if (jb.kind == 0) {
+                const double mean = s * inv;
+                double var = q * inv - mean * mean;
+                if (var < 0.0) var = 0.0;
+                jb.o1[lane] = (float)mean;
+                // double like ATen's CPU accumulate type: a float rstd moves PReLU-slope gradients of the
+                // compact fixture by 2% (ill-conditioned sums), see DESIGN.md
+                jb.o2[lane] = (float)(1.0 / sqrt(var + (double)jb.eps));
+                if (is_block0 && jb.update && jb.rm != nullptr) {
+                    const double n_ = (double)jb.count;
+                    const double unb = n_ > 1.0 ? var * n_ / (n_ - 1.0) : var;
+                    jb.rm[lane] = (float)((1.0 - jb.momentum) * (double)jb.rm[lane] + jb.momentum * mean);
+                    jb.rv[lane] = (float)((1.0 - jb.momentum) * (double)jb.rv[lane] + jb.momentum * unb);
+                }
+            } else {
+                jb.o1[lane] = (float)(s * inv);
+                jb.o2[lane] = (float)(q * inv);
+            }
         }
     }
     __syncthreads();
