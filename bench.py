@@ -88,6 +88,19 @@ def cpu_baseline(cfg, spec, aux, budget_s):
             "host_cpus": os.cpu_count()}
 
 
+def pmc_traffic(kernel, ae_form, b):
+    """HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC summary (FETCH_SIZE and
+    WRITE_SIZE collected in separate passes of this same command, profiles/r1_pmc_traffic_*.json);
+    None when there is no summary for this workload.  Counters cannot be read from inside the process."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                        f"r1_pmc_traffic_{ae_form.lower()}_b{b}.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        k = json.load(f)["kernels"].get(kernel)
+    return k["hbm_bytes_raw"] if k else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -177,6 +190,7 @@ def main():
         }
         if not args.no_roofline:
             line["roofline"] = eng.roofline_probe(b, HBM_PEAK_GBS)
+            line["roofline"]["traffic"] = pmc_traffic(line["roofline"]["kernel"], cfg["ae_form"], b)
         if args.cpu_budget > 0:
             line["cpu_baseline"] = cpu_baseline(cfg, spec, aux, args.cpu_budget)
             line["speedup_vs_cpu_baseline"] = round(value / line["cpu_baseline"]["value"], 1)

@@ -463,6 +463,7 @@ __global__ __launch_bounds__(256) void grad_materialize_kernel(GradMatArgs a) {
 
 #include "raae_conv_tiled.inc"
 #include "raae_block_fused.inc"
+#include "raae_conv_strip.inc"
 
 int slices_for(long per_channel, int C) {
     long n = (per_channel + 255) / 256;
@@ -514,6 +515,7 @@ extern "C" int raae_conv_fwd(const raae_view_t* in, int B, const raae_conv_t* cv
     ConvFwdArgs a;
     a.in = *in; a.B = B; a.cv = *cv; a.w = w; a.bias = bias; a.out = out; a.stats_kind = stats_kind;
     a.out_slope = out_slope; a.out_partials = out_partials; a.act = act;
+    if (conv_fwd_strip(a, out_nparts, (hipStream_t)stream)) RAAE_LAUNCH_RET();
     const long per_in = (long)cv->Cin * (cv->Lin + 2 * (cv->transposed ? 0 : cv->pad));
     if (conv_nw(cv) <= 1024 && (stats_kind == RAAE_OUT_RAW || cv->Cout <= CT_MAXCH) && per_in <= kTileBudget) {
         ConvFwdTArgs t;

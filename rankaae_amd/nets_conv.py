@@ -290,10 +290,16 @@ class CompactNet:
                     convs.append((ops.make_grad(w.dSh), k.cvs, vR(), m.conv_short))
                 lins = [(ops.make_grad(dE2), k.Cin, k.Lout, k.E, ops.make_view(w.E1, m.relu_excit_1.weight), m.fc2),
                         (ops.make_grad(w.dE1), k.Cin, k.E, k.Lin, vR(mask), m.fc1)]
+                # algorithmic bytes: every task reads its input view and its output gradient
+                # once and writes one slab of weight + bias gradients
+                nbytes = sum(4 * b * (cv_.Cin * cv_.Lin + cv_.Cout * cv_.Lout) + 4 * (mod.weight.numel() + cv_.Cout)
+                             for _, cv_, _, mod in convs)
+                nbytes += sum(4 * b * c_ * (e_ + l_) + 4 * (e_ * l_ + e_) for _, c_, e_, l_, _, _ in lins)
                 with eng.side_stream():
-                    ns = ops.block_wgrad(b, [(g_, cv_, v_, G_(mod.weight), G_(mod.bias)) for g_, cv_, v_, mod in convs],
-                                         [(g_, c_, e_, l_, v_, G_(mod.weight), G_(mod.bias))
-                                          for g_, c_, e_, l_, v_, mod in lins], eng.arena.n)
+                    ns = eng.probe_launch("block_wgrad", nbytes, lambda: ops.block_wgrad(
+                        b, [(g_, cv_, v_, G_(mod.weight), G_(mod.bias)) for g_, cv_, v_, mod in convs],
+                        [(g_, c_, e_, l_, v_, G_(mod.weight), G_(mod.bias)) for g_, c_, e_, l_, v_, mod in lins],
+                        eng.arena.n))
                 for (_, _, _, mod), n_ in zip(convs, ns):
                     eng.note_slabs([mod.weight, mod.bias], n_)
                 for (_, _, _, _, _, mod), n_ in zip(lins, ns[len(convs):]):

@@ -392,6 +392,12 @@ CONV_CASES = [
     ("conv", 9, 6, 8, dict(Cout=8, K=1, s=1, p=0, rep=False, g=2)),
     ("conv", 8, 4, 256, dict(Cout=4, K=11, s=1, p=5, rep=True, g=1)),
     ("conv", 8, 4, 256, dict(Cout=1, K=1, s=1, p=0, rep=False, g=1)),
+    # >= 2^20 outputs: the register-blocked large-batch forward (raae_conv_strip.inc), ragged last group
+    ("conv", 1027, 4, 256, dict(Cout=4, K=11, s=1, p=5, rep=True, g=1)),
+    ("conv", 2050, 4, 256, dict(Cout=4, K=11, s=2, p=5, rep=False, g=1)),
+    ("conv", 2049, 1, 256, dict(Cout=4, K=11, s=2, p=5, rep=True, g=1)),
+    ("conv", 8200, 4, 64, dict(Cout=4, K=7, s=2, p=3, rep=True, g=1)),
+    ("conv", 4100, 4, 64, dict(Cout=4, K=5, s=1, p=2, rep=False, g=1)),
     ("convT", 16, 6, 1, dict(Cout=8, K=2, g=1)),
     ("convT", 16, 8, 2, dict(Cout=8, K=4, g=1)),
     ("convT", 16, 6, 1, dict(Cout=8, K=8, g=2)),
@@ -463,8 +469,39 @@ def test_conv_family_fwd_bwd(kind, B, Cin, Lin, cfg):
     close(din, r["dv"] + 0.5, 5e-4, 5e-5, "din (accumulated onto 0.5)")
     tot = pdin[:nd].sum(0).cpu()
     want_din = (r["dv"] + 0.5).double()
-    close(tot[:, 0], want_din.sum((0, 2)), 1e-4, 1e-3, "din partial sum")
-    close(tot[:, 1], (want_din * r["v"].detach().double()).sum((0, 2)), 1e-4, 1e-3, "din*y partial sum")
+    # sums of B*Lin fp32 values each good to ~5e-5: the absolute error of the total grows like sqrt(B*Lin)
+    atol = max(1e-3, 5e-5 * (B * Lin) ** 0.5)
+    close(tot[:, 0], want_din.sum((0, 2)), 1e-4, atol, "din partial sum")
+    close(tot[:, 1], (want_din * r["v"].detach().double()).sum((0, 2)), 1e-4, atol, "din*y partial sum")
+
+
+@pytest.mark.parametrize("B,Cin,K,s,rep,act", [(1100, 4, 11, 1, True, 0), (2051, 1, 11, 2, True, 0),
+                                                (4100, 4, 5, 2, False, 3)])       # 3 = RAAE_OUT_SOFTPLUS
+def test_conv_fwd_large_batch_plain_view(B, Cin, K, s, rep, act):
+    """Register-blocked large-batch forward without mask / BatchNorm / PReLU on the input and with the
+    statistics switched off or on the raw output: the remaining template and flag combinations."""
+    g = torch.Generator().manual_seed(B)
+    Lin = 256 if K == 11 else 64
+    X = torch.randn(B, Cin, Lin, generator=g)
+    m = torch.nn.Conv1d(Cin, 4, K, stride=s, padding=(K - 1) // 2, padding_mode="replicate" if rep else "zeros")
+    with torch.no_grad():
+        ref = m(X)
+        if act == 3:
+            want = F.softplus(ref, beta=2)
+        else:
+            want = ref
+    Lout = ref.shape[2]
+    cv = ops.make_conv(Cin, Lin, 4, Lout, K, s, (K - 1) // 2, rep, 1, False)
+    out = torch.empty(B, 4, Lout, device=DEV)
+    pout = torch.zeros(_lib.RAAE_MAX_PARTS, 4, 2, dtype=torch.float64, device=DEV)
+    kind = _lib.OUT_RAW if act else _lib.OUT_STATS_RAW
+    n = ops.conv_fwd(ops.make_view(dev(X)), B, cv, dev(m.weight.detach()), dev(m.bias.detach()), out, kind, None,
+                     pout if kind else None, act)
+    close(out, want, 2e-5, 2e-5, "out")
+    if kind:
+        tot = pout[:n].sum(0).cpu()
+        close(tot[:, 0], ref.double().sum((0, 2)), 1e-5, 1e-3, "sum partials")
+        close(tot[:, 1], (ref.double() ** 2).sum((0, 2)), 1e-5, 1e-3, "sumsq partials")
 
 
 def test_sum3_and_grad_materialize():
