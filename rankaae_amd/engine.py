@@ -411,6 +411,9 @@ class StepEngine:
         n_side = int(self.cfg.get("side_streams", 3))
         self.side_streams = [torch.cuda.Stream(device=device) for _ in range(n_side)]
         self._side_i, self._side_used, self._events = 0, set(), []
+        # one more stream for whole FORWARD chains whose result the step does not wait for (the two forwards
+        # the reference runs only for their BatchNorm / RNG side effects): they run beside the critical chain
+        self.aux_stream = torch.cuda.Stream(device=device) if self.cfg.get("overlap_unused_forwards", True) else None
         self.cursor_start, self.cursor_stride, self._cursor_primed = 0, None, False
 
     # -- optimizers: trainer.py:333-397 (only the five that ever step under gradient reversal)
@@ -447,6 +450,31 @@ class StepEngine:
             with torch.cuda.stream(s):
                 yield
         return ctx()
+
+    def aux_branch(self):
+        """Context: launches inside go to the auxiliary stream, ordered after everything submitted so far."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            if self.aux_stream is None:
+                yield
+                return
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.aux_stream.wait_event(ev)
+            self._events.append(ev)
+            with torch.cuda.stream(self.aux_stream):
+                yield
+        return ctx()
+
+    def join_aux(self):
+        if self.aux_stream is None:
+            return
+        ev = torch.cuda.Event()
+        ev.record(self.aux_stream)
+        torch.cuda.current_stream().wait_event(ev)
+        self._events.append(ev)
 
     def join_side_streams(self):
         for s in list(self._side_used):
@@ -608,11 +636,15 @@ class StepEngine:
         lo = self.loss_out
         # trainer.py:113-114
         styles = enc.forward(E, P.spec, P.m_enc[0])
-        dec.forward(D, styles, P.m_dec[0])
+        # the reference discards this decoder output (BatchNorm statistics and RNG draws are its only effects):
+        # it runs beside phase A, which touches neither the decoder nor `styles`
+        with self.aux_branch():
+            dec.forward(D, styles, P.m_dec[0])
         # ---- phase A: adversarial (trainer.py:117-127)
         self._begin_phase(record)
         dst = self.disc.forward_backward(P.disc, P.sl_disc, styles, lo[0:1])
         enc.backward(E, P.spec, P.m_enc[0], dst)
+        self.join_aux()
         self._adam(P, "adversarial", self._slab_notes)
         # ---- phase B: rank correlation (:153-161)
         self._begin_phase(record)
@@ -632,9 +664,11 @@ class StepEngine:
         self._adam(P, "reconstruction", self._slab_notes)
         # ---- phase D: mutual information (:175-186)
         self._begin_phase(record)
-        enc.forward(E, P.spec, P.m_enc[3])          # result unused by the reference too (BN stats + RNG)
+        with self.aux_branch():                     # result unused by the reference too (BN stats + RNG):
+            enc.forward(E, P.spec, P.m_enc[3])      # beside the decoder forward, which only needs z_sample
         z_s = tape.view(P.z_sample, b, ns)
         out = dec.forward(D, z_s, P.m_dec[2])
+        self.join_aux()
         z_rec = enc.forward(E, out, P.m_enc[4])
         n = ops.mse_fwd_bwd(z_rec, z_s, b * ns, P.lpart, P.dstyles)
         ops.loss_finalize(P.lpart, n, 1.0, lo, 3, 5)
