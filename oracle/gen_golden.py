@@ -91,12 +91,12 @@ def checksum(module):
     return out
 
 
-def run_case(name):
+def run_case(name, case=None, write=True):
     from sc.clustering import trainer as T
     from sc.utils.parameter import Parameters
     from rankaae_amd.synthetic import make_spectra, write_csv
 
-    n_rows, n_points, over, data_seed, model_seed = CASES[name]
+    n_rows, n_points, over, data_seed, model_seed = case or CASES[name]
     cfg = dict(BASE_CONFIG)
     cfg.update(over)
     spec, aux, grid = make_spectra(n_rows, n_points, cfg["n_aux"], seed=data_seed)
@@ -168,6 +168,8 @@ def run_case(name):
         "loss_calls": rec, "epoch_metrics": epoch_metrics, "final_metrics": [float(x) for x in metrics],
         "losses_csv": lines, "init_checksum": init, "final_checksum": final, "val_styles_first8": styles,
     }
+    if not write:
+        return fixture
     out = os.path.join(REPO, "tests", "golden", f"ref_{name}.json")
     with open(out, "w") as f:
         json.dump(fixture, f, indent=1)
@@ -185,8 +187,36 @@ def _cpu_model():
     return "unknown"
 
 
+P3_SEEDS = [11, 22, 33, 44, 55, 66, 77, 88]
+P3_CASES = {
+    # SURVEY 8d protocol P3: >= 8 model seeds x fixed epochs; the DISTRIBUTION of the final metrics is the target
+    "p3_fc": (700, 256, dict(ae_form="FC", batch_size=64, max_epoch=6), 0),
+    "p3_compact": (700, 256, dict(ae_form="compact", batch_size=64, max_epoch=6), 0),
+}
+
+
+def run_p3(name):
+    n_rows, n_points, over, data_seed = P3_CASES[name]
+    runs = []
+    for seed in P3_SEEDS:
+        fx = run_case(f"{name}_{seed}", case=(n_rows, n_points, over, data_seed, seed), write=False)
+        runs.append({"model_seed": seed, "final_metrics": fx["final_metrics"], "epoch_metrics": fx["epoch_metrics"]})
+        print(name, seed, fx["final_metrics"])
+    cfg = dict(BASE_CONFIG)
+    cfg.update(over)
+    out = os.path.join(REPO, "tests", "golden", f"ref_{name}.json")
+    with open(out, "w") as f:
+        json.dump({"case": name, "config": cfg, "n_rows": n_rows, "n_points": n_points, "data_seed": data_seed,
+                   "metric_names": ["min_shapiro_W", "val_recon_mse", "mean_train_mi", "max_abs_spearman", "val_rank_loss"],
+                   "runs": runs, "torch": torch.__version__, "cpu_model": _cpu_model(), "threads": 1}, f, indent=1)
+    print("wrote", out)
+
+
 if __name__ == "__main__":
     _install_shims()
     which = sys.argv[1:] or list(CASES)
     for nm in which:
-        run_case(nm)
+        if nm in P3_CASES:
+            run_p3(nm)
+        else:
+            run_case(nm)

@@ -69,3 +69,43 @@ def test_trainer_end_to_end(case, rng_mode, tmp_path):
     with torch.no_grad():
         z_ref = enc(val_spec)
     assert torch.allclose(z_hip.cpu(), z_ref, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("case", ["p3_fc", "p3_compact"])
+def test_p3_statistical_parity(case, tmp_path):
+    """SURVEY 8d protocol P3: the trajectory is chaotic, so beyond teacher-forced steps the comparison is
+    statistical -- 8 model seeds x 6 epochs; the distribution of the final validation reconstruction MSE,
+    mean training mutual-information loss and validation rank loss of this engine (device Philox noise) must
+    overlap the real reference's (fixtures: oracle/gen_golden.py p3_*): difference of means within
+    3 standard errors + 10 %."""
+    import logging
+    from rankaae_amd.parameter import Parameters
+    from rankaae_amd.trainer import Trainer
+    with open(os.path.join(os.path.dirname(__file__), "golden", f"ref_{case}.json")) as f:
+        g = json.load(f)
+    ref = np.array([r["final_metrics"] for r in g["runs"]])
+    spec, aux, _ = make_spectra(g["n_rows"], g["n_points"], g["config"]["n_aux"], seed=g["data_seed"])
+    quiet = logging.getLogger("p3_quiet")
+    quiet.addHandler(logging.NullHandler())
+    quiet.propagate = False
+    got = []
+    for r in g["runs"]:
+        cfg = dict(g["config"])
+        cfg.update(rng_mode="philox", seed=r["model_seed"])
+        torch.manual_seed(r["model_seed"])
+        wd = tmp_path / f"s{r['model_seed']}"
+        wd.mkdir()
+        tr = Trainer.from_data(None, igpu=0, verbose=False, work_dir=str(wd), config_parameters=Parameters(cfg),
+                               logger=quiet, loss_logger=quiet, arrays=(spec, aux))
+        got.append([float(x) for x in tr.train()])
+    got = np.array(got)
+    assert np.all(np.isfinite(got))
+    n = len(ref)
+    for j, name in ((1, "val recon MSE"), (2, "mean train MI"), (4, "val rank loss")):
+        se = np.sqrt((ref[:, j].var(ddof=1) + got[:, j].var(ddof=1)) / n)
+        diff = abs(got[:, j].mean() - ref[:, j].mean())
+        assert diff <= 3 * se + 0.1 * abs(ref[:, j].mean()), \
+            f"{case} {name}: ours {got[:, j].mean():.5f}+-{got[:, j].std(ddof=1):.5f} vs reference " \
+            f"{ref[:, j].mean():.5f}+-{ref[:, j].std(ddof=1):.5f}"
+    # Shapiro W and the coupling metric live in [0, 1]; same ballpark
+    assert abs(got[:, 0].mean() - ref[:, 0].mean()) < 0.15 and abs(got[:, 3].mean() - ref[:, 3].mean()) < 0.25
