@@ -178,7 +178,7 @@ def main():
         value = world * args.steps / dt
         line = {
             "metric": "training steps/sec (batch=256, 256-pt spectra)", "value": round(value, 2),
-            "unit": "steps/s (five-phase steps on 256-row batches, summed over ranks)",
+            "unit": f"steps/s (five-phase steps on {b}-row batches, summed over ranks)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: {args.rows}x{cfg['dim_in']} synthetic spectra (train split "
