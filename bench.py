@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-oracle timing (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
+                    help="override an engine tuning key (side_streams, overlap_unused_forwards, fused_blocks)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -129,9 +131,16 @@ def main():
     from rankaae_amd.engine import StepEngine
     from rankaae_amd.synthetic import make_spectra
     from rankaae_amd.dataloader import split_counts
+    from rankaae_amd import _lib
+    if hasattr(_lib.load(), "raae_debug_stamps"):
+        raise SystemExit("librankaae_hip.so is a -DRAAE_STAMPS build (extra barriers and clock reads in every "
+                         "kernel): rebuild with plain rankaae_amd/csrc/build.sh before benchmarking")
 
     cfg = dict(BASE_CFG)
     cfg.update(ae_form=args.ae_form, batch_size=args.batch)
+    for kv in args.set:
+        k, v = kv.split("=", 1)
+        cfg[k] = json.loads(v)
     spec, aux, _ = make_spectra(args.rows, cfg["dim_in"], cfg["n_aux"], seed=0)
     n_train = split_counts(args.rows)[0]
     enc, dec, dis = build_models(cfg, 1234)

@@ -146,9 +146,11 @@ int raae_gather_batch(const float* spec, const float* aux, const long* idx, cons
  *   g_slabs: slab 0 of the same range; slab s at g_slabs + s*slab_stride
  *   hyper (device, 5 doubles): {lr, beta1, beta2, eps, weight_decay}
  *   step  (device int): 1-based step count, advanced by raae_step_tick BEFORE this launch
- *   decoupled=1 => AdamW (p *= 1-lr*wd), 0 => Adam (g += wd*p). */
+ *   decoupled=1 => AdamW (p *= 1-lr*wd), 0 => Adam (g += wd*p)
+ *   max_nslab: upper bound of seg_nslab over the range (host-side hint: above 16 the slabs of an element are
+ *   summed by 8 lanes instead of one thread; the result does not depend on it beyond summation order). */
 int raae_adam_step(float* p, float* m, float* v, const float* g_slabs, long slab_stride, const unsigned short* seg_nslab,
-                   long n, const double* hyper, const int* step, int decoupled, void* stream);
+                   long n, const double* hyper, const int* step, int decoupled, int max_nslab, void* stream);
 /* ====================== 1-D convolutional networks (ae_form: compact) ======================
  * Activations are [B][C][L] fp32, stored RAW (pre-activation); what a consumer sees is a *view*:
  *     value = mask * BatchNorm( PReLU(raw, slope_c) )          (each stage optional)
@@ -299,7 +301,7 @@ int raae_block_wgrad(const raae_block_wgrad_t* a, int* nslab, void* stream);
  * north star): out[i] = fixed-order sum of the slabs of element i -- the flat gradient that is then
  * averaged across ranks with one RCCL all-reduce per phase and fed to raae_adam_step as a single slab. */
 int raae_slab_reduce(const float* g_slabs, long slab_stride, const unsigned short* seg_nslab, long n, float* out,
-                     void* stream);
+                     int max_nslab, void* stream);
 /* once per training step: steps[i] += 1 for every bit i set in mask; rng_counter[0] += 1;
  * cursor[0] += cursor_inc (epoch row cursor of raae_gather_batch) */
 int raae_step_tick(int* steps, int n, unsigned mask, unsigned long long* rng_counter, int* cursor, int cursor_inc,
@@ -324,7 +326,7 @@ int raae_event_destroy(void* ev);
 int raae_stream_sync(void* stream);
 const char* raae_error_string(int code);
 int raae_device_info(int* cu_count, int* lds_bytes, char* name, int name_len);
-#define RAAE_ABI_VERSION 2
+#define RAAE_ABI_VERSION 3
 int raae_abi_version(void);
 /* First 16 hex digits of sha256 over include/rankaae_hip.h + csrc/raae_*.{h,inc,hip} at build time
  * (build.sh); the Python loader recomputes it and refuses a library built from other sources. */

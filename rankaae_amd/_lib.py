@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librankaae_hip.so")
 
 RAAE_MAX_PARTS = 512
-ABI_VERSION = 2
+ABI_VERSION = 3
 IN_NONE, IN_PRELU_BN_DROP, IN_PRELU_DROP = 0, 1, 2
 OUT_RAW, OUT_STATS_PRELU, OUT_STATS_RAW, OUT_SOFTPLUS, OUT_RELU = 0, 1, 2, 3, 4
 G_DIRECT, G_SOFTPLUS, G_PRELU_BN, G_PRELU, G_RELU = 0, 1, 2, 3, 4
@@ -124,7 +124,7 @@ SIGNATURES = {
     "raae_scale_by_dev": (_I, [_P, _P, _F, _L, _P, _P]),
     "raae_loss_finalize": (_I, [_P, _I, _F, _P, _I, _I, _P]),
     "raae_gather_batch": (_I, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P]),
-    "raae_adam_step": (_I, [_P, _P, _P, _P, _L, _P, _L, _P, _P, _I, _P]),
+    "raae_adam_step": (_I, [_P, _P, _P, _P, _L, _P, _L, _P, _P, _I, _I, _P]),
     "raae_conv_fwd": (_I, [_PV, _I, _PC, _P, _P, _P, _I, _P, _P, _PI, _I, _P]),
     "raae_conv_bwd_data": (_I, [_PG, _I, _PC, _P, _PV, _P, _I, _P, _PI, _P]),
     "raae_conv_bwd_weight": (_I, [_PG, _I, _PC, _PV, _P, _P, _P, _L, _PI, _P]),
@@ -138,7 +138,7 @@ SIGNATURES = {
     "raae_block_bwd_b": (_I, [C.POINTER(BlockBwdBT), _PI, _P]),
     "raae_block_bwd_a": (_I, [C.POINTER(BlockBwdAT), _PI, _P]),
     "raae_block_wgrad": (_I, [C.POINTER(BlockWgradT), _PI, _P]),
-    "raae_slab_reduce": (_I, [_P, _L, _P, _L, _P, _P]),
+    "raae_slab_reduce": (_I, [_P, _L, _P, _L, _P, _I, _P]),
     "raae_step_tick": (_I, [_P, _I, C.c_uint, _P, _P, _I, _P]),
     "raae_rng_fill": (_I, [_P, _P, _P, _I, _L, C.c_ulonglong, _P, _P]),
     "raae_graph_begin": (_I, [_P]),

@@ -9,7 +9,8 @@ FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function $RA
 # every object depends on every header / .inc; the digest of all sources is baked into the library
 # (raae_source_digest) so that the Python loader can refuse a stale build.
 DIGEST=$(cat ../../include/rankaae_hip.h raae_*.h raae_*.inc raae_*.hip | sha256sum | cut -c1-16)
-if [ "$(cat .digest 2>/dev/null)" != "$DIGEST" ]; then rm -f raae_*.o; echo "$DIGEST" > .digest; fi
+# objects are rebuilt when the sources OR the extra flags change (the digest baked into the library is of the sources)
+if [ "$(cat .digest 2>/dev/null)" != "$DIGEST $RAAE_EXTRA_FLAGS" ]; then rm -f raae_*.o; echo "$DIGEST $RAAE_EXTRA_FLAGS" > .digest; fi
 FLAGS="$FLAGS -DRAAE_SOURCE_DIGEST=\"$DIGEST\""
 OBJS=""
 for f in raae_*.hip; do

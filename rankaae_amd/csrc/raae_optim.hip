@@ -56,6 +56,63 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, float* m, float* v,
     }
 }
 
+// Same update with the slabs of an element spread over 8 lanes: for ranges whose tensors have many slabs.
+__global__ __launch_bounds__(256) void adam_wide_kernel(float* p, float* m, float* v, const float* g_slabs, long slab_stride,
+                                                   const unsigned short* seg_nslab, long n, const double* hyper,
+                                                   const int* step, int decoupled) {
+    __shared__ float s_sc[8];
+    if (threadIdx.x == 0) {
+        const double lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
+        const double t = (double)step[0];
+        const double bc1 = 1.0 - pow(b1, t), bc2 = 1.0 - pow(b2, t);
+        s_sc[0] = (float)(1.0 - lr * wd);      // AdamW decay factor
+        s_sc[1] = (float)(1.0 - b1);           // lerp weight
+        s_sc[2] = (float)b2;
+        s_sc[3] = (float)(1.0 - b2);
+        s_sc[4] = (float)(-(lr / bc1));        // -step_size
+        s_sc[5] = (float)sqrt(bc2);
+        s_sc[6] = (float)eps;
+        s_sc[7] = (float)wd;
+    }
+    __syncthreads();
+    const float decay = s_sc[0], w1 = s_sc[1], b2f = s_sc[2], omb2 = s_sc[3], nstep = s_sc[4], bc2s = s_sc[5],
+                epsf = s_sc[6], wdf = s_sc[7];
+    // A wave owns 8 consecutive elements; lane = chunk*8 + element: the slabs of an element are spread over
+    // 8 lanes (chunk c sums slabs c, c+8, ... eight loads deep), joined by a fixed xor-shuffle tree.  With one
+    // thread per element the 256 slabs of a conv weight were 32 dependent round trips (28 us per step phase).
+    const int lane = threadIdx.x & 63, el = lane & 7, ch = lane >> 3;
+    const long wave0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
+    for (long base = wave0; base < n; base += (long)gridDim.x * 32) {
+        const long i = base + el;                       // n is a multiple of 64: i < n whenever base < n
+        const int ns = seg_nslab[i >> 6];
+        if (ns == 0) continue;                          // uniform over the wave (8 elements share a segment)
+        float g = 0.f;
+        for (int s = ch; s < ns; s += 64) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = s + 8 * u;
+                t[u] = g_slabs[(size_t)(r < ns ? r : ch) * slab_stride + i];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) g += (s + 8 * u < ns) ? t[u] : 0.f;
+        }
+        g += __shfl_xor(g, 8, 64);
+        g += __shfl_xor(g, 16, 64);
+        g += __shfl_xor(g, 32, 64);
+        if (ch != 0) continue;
+        float pv = p[i];
+        if (decoupled) pv = pv * decay; else if (wdf != 0.f) g = g + wdf * pv;
+        float mv = m[i], vv = v[i];
+        mv = mv + w1 * (g - mv);
+        vv = vv * b2f;
+        vv = vv + (omb2 * g) * g;
+        const float denom = sqrtf(vv) / bc2s + epsf;
+        pv = pv + (nstep * mv) / denom;
+        p[i] = pv; m[i] = mv; v[i] = vv;
+    }
+}
+
 __global__ void tick_kernel(int* steps, int n, unsigned mask, unsigned long long* rng_counter, int* cursor,
                             int cursor_inc) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -116,12 +173,19 @@ __global__ __launch_bounds__(256) void rng_fill_kernel(float* tape, const int* s
 
 extern "C" int raae_adam_step(float* p, float* m, float* v, const float* g_slabs, long slab_stride,
                               const unsigned short* seg_nslab, long n, const double* hyper, const int* step,
-                              int decoupled, void* stream) {
-    RAAE_CHECK_ARG(p && m && v && g_slabs && seg_nslab && hyper && step && n > 0 && (n % 64) == 0);
-    long g = (n + 1023) / 1024;
-    if (g > 1024) g = 1024;
-    hipLaunchKernelGGL(adam_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, p, m, v, g_slabs, slab_stride,
-                       seg_nslab, n, hyper, step, decoupled);
+                              int decoupled, int max_nslab, void* stream) {
+    RAAE_CHECK_ARG(p && m && v && g_slabs && seg_nslab && hyper && step && n > 0 && (n % 64) == 0 && max_nslab >= 0);
+    if (max_nslab > 16) {
+        long g = (n + 31) / 32;                 // 32 elements per workgroup (8 lanes per element)
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(adam_wide_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, p, m, v, g_slabs, slab_stride,
+                           seg_nslab, n, hyper, step, decoupled);
+    } else {
+        long g = (n + 255) / 256;               // one element per thread
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(adam_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, p, m, v, g_slabs, slab_stride,
+                           seg_nslab, n, hyper, step, decoupled);
+    }
     RAAE_LAUNCH_RET();
 }
 
@@ -218,14 +282,47 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* g_slabs, 
         out[i] = g;
     }
 }
+// the summation tree of adam_wide_kernel (8 lanes per element), so that the data-parallel path adds the
+// slabs of a rank in exactly the order the single-GPU update does
+__global__ __launch_bounds__(256) void slab_reduce_wide_kernel(const float* g_slabs, long slab_stride,
+                                                               const unsigned short* seg_nslab, long n, float* out) {
+    const int lane = threadIdx.x & 63, el = lane & 7, ch = lane >> 3;
+    const long wave0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
+    for (long base = wave0; base < n; base += (long)gridDim.x * 32) {
+        const long i = base + el;
+        const int ns = seg_nslab[i >> 6];
+        float g = 0.f;
+        for (int s = ch; s < ns; s += 64) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = s + 8 * u;
+                t[u] = g_slabs[(size_t)(r < ns ? r : ch) * slab_stride + i];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) g += (s + 8 * u < ns) ? t[u] : 0.f;
+        }
+        g += __shfl_xor(g, 8, 64);
+        g += __shfl_xor(g, 16, 64);
+        g += __shfl_xor(g, 32, 64);
+        if (ch == 0) out[i] = g;
+    }
+}
 }  // namespace
 
 extern "C" int raae_slab_reduce(const float* g_slabs, long slab_stride, const unsigned short* seg_nslab, long n,
-                                float* out, void* stream) {
-    RAAE_CHECK_ARG(g_slabs && seg_nslab && out && n > 0 && (n % 64) == 0);
-    long g = (n + 1023) / 1024;
-    if (g > 1024) g = 1024;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, g_slabs, slab_stride,
-                       seg_nslab, n, out);
+                                float* out, int max_nslab, void* stream) {
+    RAAE_CHECK_ARG(g_slabs && seg_nslab && out && n > 0 && (n % 64) == 0 && max_nslab >= 0);
+    if (max_nslab > 16) {
+        long g = (n + 31) / 32;
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(slab_reduce_wide_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, g_slabs, slab_stride,
+                           seg_nslab, n, out);
+    } else {
+        long g = (n + 255) / 256;
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, g_slabs, slab_stride,
+                           seg_nslab, n, out);
+    }
     RAAE_LAUNCH_RET();
 }

@@ -413,7 +413,10 @@ class StepEngine:
         self._side_i, self._side_used, self._events = 0, set(), []
         # one more stream for whole FORWARD chains whose result the step does not wait for (the two forwards
         # the reference runs only for their BatchNorm / RNG side effects): they run beside the critical chain
-        self.aux_stream = torch.cuda.Stream(device=device) if self.cfg.get("overlap_unused_forwards", True) else None
+        # (pays off for the conv networks, +7 %; with the dense ones -- 5 us kernels -- the cross-stream
+        # dependencies of the graph cost more than the overlap gains: 1018 -> 918 steps/s, so it is off there)
+        overlap = self.cfg.get("overlap_unused_forwards", self.cfg["ae_form"] == "compact")
+        self.aux_stream = torch.cuda.Stream(device=device) if overlap else None
         self.cursor_start, self.cursor_stride, self._cursor_primed = 0, None, False
 
     # -- optimizers: trainer.py:333-397 (only the five that ever step under gradient reversal)
@@ -559,6 +562,7 @@ class StepEngine:
         P.dout = torch.empty(b, self.L, device=dev)
         P.lpart = torch.zeros(RAAE_MAX_PARTS, dtype=torch.float64, device=dev)
         P.seg = {n: torch.zeros(self.arena.n // 64, dtype=torch.int16, device=dev) for n in OPT_NAMES}
+        P.max_slab = {n: 0 for n in OPT_NAMES}
         P.graphs = {}
         self.plans[b] = P
         return P
@@ -568,19 +572,20 @@ class StepEngine:
         o = self.opts[name]
         if notes_host is not None:
             P.seg[name].copy_(torch.from_numpy(notes_host))
+            P.max_slab[name] = int(notes_host.max())      # host-side hint for the Adam kernel's lane split
         self.join_side_streams()
         if self.phase_hook is not None:      # debugging / parity tests: gradients before the update
             self.phase_hook(name, P)
         lo, n = o.lo, o.hi - o.lo
         if self.world_size > 1:
             # flat gradient -> RCCL mean over ranks -> Adam on the averaged single slab
-            ops.slab_reduce(self.G[0, lo:], self.arena.n, P.seg[name][lo // 64:], n, self.G_flat[lo:])
+            ops.slab_reduce(self.G[0, lo:], self.arena.n, P.seg[name][lo // 64:], n, self.G_flat[lo:], P.max_slab[name])
             self._collective(self.G_flat[lo:o.hi])
             ops.adam_step(self.arena.P[lo:], o.m, o.v, self.G_flat[lo:], self.arena.n, self.seg_ones[lo // 64:], n,
-                          o.hyper, self.steps_dev[o.index:], self.decoupled)
+                          o.hyper, self.steps_dev[o.index:], self.decoupled, 1)
         else:
             ops.adam_step(self.arena.P[lo:], o.m, o.v, self.G[0, lo:], self.arena.n, P.seg[name][lo // 64:], n,
-                          o.hyper, self.steps_dev[o.index:], self.decoupled)
+                          o.hyper, self.steps_dev[o.index:], self.decoupled, P.max_slab[name])
         if self.post_phase_hook is not None:  # parity tests: teacher forcing at phase granularity
             self.post_phase_hook(name, P)
 

@@ -129,15 +129,16 @@ def gather_batch(spec, aux, idx, cursor, noise, spec_noise, B, L, n_aux, spec_ou
                                         _stream()), "raae_gather_batch")
 
 
-def adam_step(p, m, v, g_slabs, slab_stride, seg_nslab, n, hyper, step, decoupled):
+def adam_step(p, m, v, g_slabs, slab_stride, seg_nslab, n, hyper, step, decoupled, max_nslab=512):
     check(_lib.load().raae_adam_step(_ptr(p), _ptr(m), _ptr(v), _ptr(g_slabs), slab_stride,
                                      _ptr(seg_nslab, torch.int16), n, _ptr(hyper, torch.float64),
-                                     _ptr(step, torch.int32), 1 if decoupled else 0, _stream()), "raae_adam_step")
+                                     _ptr(step, torch.int32), 1 if decoupled else 0, int(max_nslab), _stream()),
+          "raae_adam_step")
 
 
-def slab_reduce(g_slabs, slab_stride, seg_nslab, n, out):
+def slab_reduce(g_slabs, slab_stride, seg_nslab, n, out, max_nslab=512):
     check(_lib.load().raae_slab_reduce(_ptr(g_slabs), slab_stride, _ptr(seg_nslab, torch.int16), n, _ptr(out),
-                                       _stream()), "raae_slab_reduce")
+                                       int(max_nslab), _stream()), "raae_slab_reduce")
 
 
 def step_tick(steps, n, mask, rng_counter, cursor, cursor_inc):

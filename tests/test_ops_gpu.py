@@ -292,12 +292,34 @@ def test_adam_matches_torch(decoupled, wd):
         ref.grad = grad.clone()
         opt.step()
         ops.step_tick(step, 4, 0b0101, rngc, cursor, 256)
-        ops.adam_step(p, m, v, dev(slabs), n, seg, n, hyper, step[2:], decoupled)
+        ops.adam_step(p, m, v, dev(slabs), n, seg, n, hyper, step[2:], decoupled, max_nslab=(3 if it % 2 else 40))
     torch.cuda.synchronize()
     assert step.tolist() == [5, 0, 5, 0] and int(rngc) == 5 and int(cursor) == 5 * 256
     pr = ref.detach().clone()
     pr[5 * 64:6 * 64] = p0[5 * 64:6 * 64]
     close(p, pr, 2e-6, 2e-7, "params after 5 steps")
+
+
+def test_adam_many_slabs_lane_split():
+    """Ranges with many gradient slabs take the 8-lanes-per-element kernel; same result as a host sum."""
+    g = torch.Generator().manual_seed(5)
+    n, rows = 64 * 6, 200
+    slabs = torch.randn(rows, n, generator=g)
+    counts = [200, 37, 0, 8, 65, 1]
+    seg = torch.tensor(counts, dtype=torch.int16, device=DEV)
+    p0 = torch.randn(n, generator=g)
+    hyper = torch.tensor([0.01, 0.9, 0.999, 1e-8, 0.01], dtype=torch.float64, device=DEV)
+    step = torch.ones(1, dtype=torch.int32, device=DEV)
+    out = []
+    for hint in (8, 200):                       # per-thread kernel, lane-split kernel
+        p, m, v = dev(p0), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        ops.adam_step(p, m, v, dev(slabs), n, seg, n, hyper, step, True, max_nslab=hint)
+        out.append((p.cpu(), m.cpu(), v.cpu()))
+    grad = torch.stack([slabs[:c, 64 * i:64 * (i + 1)].double().sum(0) for i, c in enumerate(counts)]).reshape(-1)
+    close(out[1][1], 0.1 * grad.float(), 1e-5, 1e-6, "m = (1-beta1) * sum of the segment's slabs")
+    for a, b in zip(out[0], out[1]):
+        close(a, b, 1e-5, 1e-6, "lane-split vs per-thread")
+    assert torch.equal(out[1][0][128:192], p0[128:192]), "segment without slabs untouched"
 
 
 def test_rng_fill_statistics():
