@@ -789,6 +789,8 @@ extern "C" int raae_block_bwd_a(const raae_block_bwd_a_t* in, int* nparts, void*
     RAAE_LAUNCH_RET();
 }
 
+// workgroups per weight-gradient task (= slabs it writes); 64 -> 128: +2 % at B=256, +18 % at B=4096
+static const int kWgradTaskGrid = 128;
 extern "C" int raae_block_wgrad(const raae_block_wgrad_t* in, int* nslab, void* stream) {
     RAAE_CHECK_ARG(in && nslab && in->B > 0 && in->n_conv >= 0 && in->n_conv <= 4 && in->n_lin >= 0 && in->n_lin <= 2 &&
                    in->n_conv + in->n_lin > 0);
@@ -809,7 +811,7 @@ extern "C" int raae_block_wgrad(const raae_block_wgrad_t* in, int* nslab, void* 
         t.slab_stride = in->slab_stride; t.sh_in = lg2(cv->Lin); t.sh_out = lg2(cv->Lout);
         t.S = pick_S(per, cv->transposed ? cv->Lin : cv->Lout, in->B, kTileBudget, 256);
         t.ngroups = (in->B + t.S - 1) / t.S;
-        const int grid = t.ngroups < 64 ? t.ngroups : 64;
+        const int grid = t.ngroups < kWgradTaskGrid ? t.ngroups : kWgradTaskGrid;
         m.first[m.ntask] = total; m.is_conv[m.ntask] = 1; m.idx[m.ntask] = i; nslab[m.ntask] = grid;
         total += grid; ++m.ntask;
         const size_t d = sizeof(float) * (size_t)t.S * per;
@@ -827,7 +829,7 @@ extern "C" int raae_block_wgrad(const raae_block_wgrad_t* in, int* nslab, void* 
         t.slab_stride = in->slab_stride; t.sh_in = lg2(c.Lin); t.sh_e = lg2(c.E);
         t.S = pick_S(per, c.C, in->B, kTileBudget, 64);
         t.ngroups = (in->B + t.S - 1) / t.S;
-        const int grid = t.ngroups < 64 ? t.ngroups : 64;
+        const int grid = t.ngroups < kWgradTaskGrid ? t.ngroups : kWgradTaskGrid;
         m.first[m.ntask] = total; m.is_conv[m.ntask] = 0; m.idx[m.ntask] = i; nslab[m.ntask] = grid;
         total += grid; ++m.ntask;
         const size_t d = sizeof(float) * (size_t)t.S * per;
