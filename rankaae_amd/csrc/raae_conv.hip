@@ -756,7 +756,7 @@ extern "C" int raae_block_bwd_b(const raae_block_bwd_b_t* in, int* nparts, void*
     a.S = pick_S(per, widest, a.B, kTileBudget, 256);
     a.ngroups = (a.B + a.S - 1) / a.S;
     a.sh_l1 = lg2(a.L1); a.sh_lout = lg2(a.Lout);
-    const int grid = a.ngroups < 256 ? a.ngroups : 256;
+    const int grid = a.ngroups < 512 ? a.ngroups : 512;
     if (nparts) *nparts = grid;
     const size_t lds = sizeof(float) * ((size_t)a.S * per + conv_nw(&a.cv2) + (a.has_excit ? conv_nw(&a.cve) : 0));
     hipLaunchKernelGGL(block_bwd_b_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
@@ -782,7 +782,7 @@ extern "C" int raae_block_bwd_a(const raae_block_bwd_a_t* in, int* nparts, void*
     a.S = pick_S(per, widest, a.B, kTileBudget, 256);
     a.ngroups = (a.B + a.S - 1) / a.S;
     a.sh_lin = lg2(a.Lin); a.sh_l1 = lg2(a.L1); a.sh_lout = lg2(a.Lout); a.sh_e = lg2(a.E);
-    const int grid = a.ngroups < 256 ? a.ngroups : 256;
+    const int grid = a.ngroups < 512 ? a.ngroups : 512;
     if (nparts) *nparts = grid;
     const size_t lds = sizeof(float) * ((size_t)a.S * per + wfl);
     hipLaunchKernelGGL(block_bwd_a_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
