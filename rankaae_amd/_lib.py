@@ -168,6 +168,10 @@ def load():
         raise HipLibraryMissing(
             f"{LIB_PATH} not found: build it with rankaae_amd/csrc/build.sh (or __graft_entry__.build()). "
             "rankaae_amd has no CPU or PyTorch fallback for the training path.")
+    # PyTorch ships its own libamdhip64; if this library were loaded first it would pull in the system copy and
+    # the process would hold two HIP runtimes (kernels registered with one, the device owned by the other:
+    # "no ROCm-capable device is detected").  Importing torch first makes both resolve to the same runtime.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)     # AttributeError if the symbol is missing
