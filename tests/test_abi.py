@@ -39,3 +39,10 @@ def test_bn_struct_layout_matches_header():
     # raae_bn_t: ptr, int, float, ptr, ptr, float, float, int  (natural alignment, 48 bytes)
     assert ctypes.sizeof(_lib.BnT) == 48
     assert _lib.BnT.running_mean.offset == 16 and _lib.BnT.momentum.offset == 32
+
+
+def test_graft_entry_build_runs():
+    """The driver's "does it build" hook: compiles (a no-op when the objects are current), loads the library
+    and imports the package and the checker."""
+    import __graft_entry__ as g
+    g.build()
