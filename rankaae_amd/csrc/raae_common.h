@@ -132,6 +132,37 @@ __device__ __forceinline__ void bnbwd_prologue(const double* partials, int npart
 }
 
 
+
+// Sum NV (power of two) doubles per lane over groups of `width` consecutive lanes (power of two, NV <= width
+// <= 64) with a halving butterfly: log2(NV) exchange steps that halve the number of live values, then plain
+// xor steps.  Afterwards lane l holds in v[0] the group total of value index group_multi_slot<NV>(l)
+// (NV + log2(width/NV) shuffles instead of NV * log2(width)).
+template <int NV>
+__device__ __forceinline__ void group_multi_sum(double (&v)[NV], int lane, int width) {
+    int half = NV >> 1;
+#pragma unroll
+    for (int o = 1; o < NV; o <<= 1) {
+        const bool up = (lane & o) != 0;
+#pragma unroll
+        for (int i = 0; i < NV / 2; ++i) {
+            if (i < half) {
+                const double send = up ? v[i] : v[i + half];
+                const double keep = up ? v[i + half] : v[i];
+                v[i] = keep + __shfl_xor(send, o, 64);
+            }
+        }
+        half >>= 1;
+    }
+    for (int o = NV; o < width; o <<= 1) v[0] += __shfl_xor(v[0], o, 64);
+}
+template <int NV>
+__device__ __forceinline__ int group_multi_slot(int lane) {
+    int idx = 0, half = NV >> 1;
+#pragma unroll
+    for (int o = 1; o < NV; o <<= 1) { if (lane & o) idx += half; half >>= 1; }
+    return idx;
+}
+
 // Copy the kernel's by-value argument struct (first and only parameter, offset 0 of the kernarg segment)
 // into LDS with ONE coalesced vector load per thread.  Scalar s_loads of a 600-byte struct come out as a
 // chain of dependent cache-line misses (the kernarg buffer is fresh for every launch): several

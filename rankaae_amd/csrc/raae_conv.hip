@@ -810,6 +810,7 @@ extern "C" int raae_block_wgrad(const raae_block_wgrad_t* in, int* nslab, void* 
         RAAE_CHECK_ARG(t.a.nw <= 1024 && per <= kTileBudget);
         t.slab_stride = in->slab_stride; t.sh_in = lg2(cv->Lin); t.sh_out = lg2(cv->Lout);
         t.S = pick_S(per, cv->transposed ? cv->Lin : cv->Lout, in->B, kTileBudget, 256);
+        { const int scap = (in->B + kWgradTaskGrid - 1) / kWgradTaskGrid; if (t.S > scap) t.S = scap; }   // parallelism from workgroups, not from samples per group
         t.ngroups = (in->B + t.S - 1) / t.S;
         const int grid = t.ngroups < kWgradTaskGrid ? t.ngroups : kWgradTaskGrid;
         m.first[m.ntask] = total; m.is_conv[m.ntask] = 1; m.idx[m.ntask] = i; nslab[m.ntask] = grid;
@@ -828,6 +829,7 @@ extern "C" int raae_block_wgrad(const raae_block_wgrad_t* in, int* nslab, void* 
         RAAE_CHECK_ARG(per <= kTileBudget);
         t.slab_stride = in->slab_stride; t.sh_in = lg2(c.Lin); t.sh_e = lg2(c.E);
         t.S = pick_S(per, c.C, in->B, kTileBudget, 64);
+        { const int scap = (in->B + kWgradTaskGrid - 1) / kWgradTaskGrid; if (t.S > scap) t.S = scap; }   // parallelism from workgroups, not from samples per group
         t.ngroups = (in->B + t.S - 1) / t.S;
         const int grid = t.ngroups < kWgradTaskGrid ? t.ngroups : kWgradTaskGrid;
         m.first[m.ntask] = total; m.is_conv[m.ntask] = 0; m.idx[m.ntask] = i; nslab[m.ntask] = grid;
