@@ -819,6 +819,21 @@ class StepEngine:
                 "batch": B, "avg_launch_us": round(us, 2), "algorithmic_bytes": nbytes,
                 "achieved": round(ach, 1), "unit": "GB/s", "frac": round(ach / peak_gbs, 4)}
 
+    @_on_stream
+    def reconstruct(self, spec):
+        """Eval-mode ``styles = Encoder(spec)``, ``spec_out = Decoder(styles)`` for ``[n, L]`` device rows --
+        the latent-space export of the reference's report tool (sc/report/analysis_new.py:94-129)."""
+        n = spec.shape[0]
+        key = ("recon", n)
+        if key not in self.plans:
+            R = StepPlan()
+            R.enc, R.dec = self.enc.alloc(n), self.dec.alloc(n)
+            self.plans[key] = R
+        R = self.plans[key]
+        z = self.enc.forward(R.enc, spec, None, train=False)
+        out = self.dec.forward(R.dec, z, None, train=False)
+        return z.clone(), out.clone()
+
     def phase_gradient(self, P, name):
         """Flat gradient (fixed-order slab sum) of optimizer ``name``'s arena range -- what the
         fused Adam kernel consumes.  For tests and debugging."""

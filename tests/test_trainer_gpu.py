@@ -109,3 +109,48 @@ def test_p3_statistical_parity(case, tmp_path):
             f"{ref[:, j].mean():.5f}+-{ref[:, j].std(ddof=1):.5f}"
     # Shapiro W and the coupling metric live in [0, 1]; same ballpark
     assert abs(got[:, 0].mean() - ref[:, 0].mean()) < 0.15 and abs(got[:, 3].mean() - ref[:, 3].mean()) < 0.25
+
+
+def test_latent_export_matches_exported_modules(tmp_path):
+    """``Reconstruct`` (sc/report/analysis_new.py:94-129) on the HIP engine: the three text files in
+    ``np.savetxt``'s default format, one row per spectrum, equal to what the saved ``final.pt`` modules (plain
+    PyTorch forward, the reference report's own consumer) compute."""
+    import logging
+    from rankaae_amd.export import Reconstruct
+    from rankaae_amd.parameter import Parameters
+    from rankaae_amd.trainer import Trainer
+    with open(os.path.join(os.path.dirname(__file__), "golden", "ref_compact_small.json")) as f:
+        g = json.load(f)
+    cfg = dict(g["config"])
+    cfg.update(rng_mode="philox", seed=3, max_epoch=1)
+    spec, aux, _ = make_spectra(g["n_rows"], g["n_points"], cfg["n_aux"], seed=g["data_seed"])
+    quiet = logging.getLogger("export_quiet")
+    quiet.addHandler(logging.NullHandler())
+    quiet.propagate = False
+    torch.manual_seed(7)
+    tr = Trainer.from_data(None, igpu=0, verbose=False, work_dir=str(tmp_path), config_parameters=Parameters(cfg),
+                           logger=quiet, loss_logger=quiet, arrays=(spec, aux))
+    tr.train()
+
+    class DS:
+        pass
+    ds = DS()
+    ds.spec = spec[-105:]                       # the test split of the reference's 70/15/15 cut
+    ev = Reconstruct(name="recon")
+    res = ev.evaluate(ds, tr, path_to_save=str(tmp_path))
+    styles = np.loadtxt(tmp_path / "recon_styles.txt")
+    spec_out = np.loadtxt(tmp_path / "recon_spec_out.txt")
+    spec_in = np.loadtxt(tmp_path / "recon_spec_in.txt")
+    assert styles.shape == (105, cfg["nstyle"]) and spec_out.shape == (105, cfg["dim_out"])
+    assert np.array_equal(spec_in.astype(np.float32), ds.spec.astype(np.float32))
+    with open(tmp_path / "recon_styles.txt") as f:
+        first = f.readline().split(" ")
+    assert len(first) == cfg["nstyle"] and len(first[0].strip()) in (24, 25) and "e" in first[0]   # %.18e
+    model = torch.load(os.path.join(str(tmp_path), "final.pt"), map_location="cpu", weights_only=False)
+    enc, dec = model["Encoder"].eval(), model["Decoder"].eval()
+    with torch.no_grad():
+        z = enc(torch.tensor(ds.spec, dtype=torch.float32))
+        y = dec(z)
+    assert np.allclose(styles, z.numpy(), rtol=1e-3, atol=1e-4)
+    assert np.allclose(spec_out, y.numpy(), rtol=1e-3, atol=1e-4)
+    assert np.array_equal(res["styles"], styles.astype(np.float32))
