@@ -88,6 +88,31 @@ def cpu_baseline(cfg, spec, aux, budget_s):
             "host_cpus": os.cpu_count()}
 
 
+def epoch_inclusive(cfg, spec, aux, epochs=8):
+    """SURVEY 8d asks for train-only AND epoch-inclusive throughput: ``Trainer.train`` with its per-epoch
+    validation forward, five validation losses, Shapiro / Spearman metrics (scipy, host, as the reference) and
+    the scheduler step; epochs 3.. are timed (the first two emit and capture the graphs)."""
+    import logging
+    import tempfile
+    from rankaae_amd.parameter import Parameters
+    from rankaae_amd.trainer import Trainer
+    quiet = logging.getLogger("bench_quiet")
+    quiet.addHandler(logging.NullHandler())
+    quiet.propagate = False
+    c = dict(cfg)
+    c.update(max_epoch=epochs, rng_mode="philox", seed=1234)
+    stamps = []
+    with tempfile.TemporaryDirectory() as wd:
+        tr = Trainer.from_data(None, igpu=torch.cuda.current_device(), verbose=False, work_dir=wd,
+                               config_parameters=Parameters(c), logger=quiet, loss_logger=quiet, arrays=(spec, aux))
+        steps_per_epoch = len(tr.train_loader)
+        tr.train(callback=lambda ep, m: (torch.cuda.synchronize(), stamps.append(time.perf_counter())))
+    dt = stamps[-1] - stamps[1]                     # epochs 2 .. epochs-1
+    n = (len(stamps) - 2) * steps_per_epoch
+    return {"value": round(n / dt, 2), "unit": "steps/s including per-epoch validation, metrics and scheduler",
+            "steps_per_epoch": steps_per_epoch, "epochs_timed": len(stamps) - 2, "ms_per_epoch": round(1e3 * dt / (len(stamps) - 2), 2)}
+
+
 def pmc_traffic(kernel, ae_form, b):
     """HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC summary (FETCH_SIZE and
     WRITE_SIZE collected in separate passes of this same command, profiles/r1_pmc_traffic_*.json);
@@ -112,6 +137,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-oracle timing (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-epoch", action="store_true", help="skip the epoch-inclusive (validation + metrics) timing")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
                     help="override an engine tuning key (side_streams, overlap_unused_forwards, fused_blocks)")
     args = ap.parse_args()
@@ -200,6 +226,8 @@ def main():
         if not args.no_roofline:
             line["roofline"] = eng.roofline_probe(b, HBM_PEAK_GBS)
             line["roofline"]["traffic"] = pmc_traffic(line["roofline"]["kernel"], cfg["ae_form"], b)
+        if not args.no_epoch and world == 1:
+            line["epoch_inclusive"] = epoch_inclusive(cfg, spec, aux)
         if args.cpu_budget > 0:
             line["cpu_baseline"] = cpu_baseline(cfg, spec, aux, args.cpu_budget)
             line["speedup_vs_cpu_baseline"] = round(value / line["cpu_baseline"]["value"], 1)
