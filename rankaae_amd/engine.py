@@ -912,22 +912,43 @@ class StepEngine:
         if self.rng_mode == "host":
             torch.empty((), dtype=torch.int64).random_()     # the val DataLoader iterator's _base_seed draw
             V.tape.fill_host()
+
+        def emit():
+            if self.rng_mode != "host":
+                ops.rng_fill(V.tape.buf, V.tape.seg_desc, V.tape.seg_scale, len(V.tape.segs), V.tape.total,
+                             self.seed ^ 0x5EED, self.rng_counter)
+            z = self.enc.forward(V.enc, val_spec, None, train=False)
+            out = self.dec.forward(V.dec, z, None, train=False)
+            n = ops.recon_loss_fwd_bwd(val_spec, out, nv, self.L, False, V.lpart, None)
+            ops.loss_finalize(V.lpart, n, 1.0, V.out, 2)
+            ops.rank_loss_fwd_bwd(val_aux, self.n_aux, z, ns, nv, self.n_aux, c["kendall_activation"], V.rank_work,
+                                  V.out[1:2], None)
+            n = ops.smooth_loss_fwd_bwd(out, nv, self.L, self.taps, V.lpart, None)
+            ops.loss_finalize(V.lpart, n, 1.0, V.out, 4)
+            z_s = V.tape.view(V.z_sample, nv, ns)
+            out2 = self.dec.forward(V.dec, z_s, None, train=False)
+            z_rec = self.enc.forward(V.enc2, out2, None, train=False)
+            n = ops.mse_fwd_bwd(z_rec, z_s, nv * ns, V.lpart, None)
+            ops.loss_finalize(V.lpart, n, 1.0, V.out, 3)
+            self.disc.forward_backward(V.disc, V.sl_disc, z, V.out[0:1], train=False)
+            return z
+
+        # like the training step: eager once, captured on the second call, replayed afterwards (the inputs must
+        # then be the same device tensors: the trainer validates on one resident split)
+        same = getattr(V, "inputs", None) == (val_spec.data_ptr(), val_aux.data_ptr())
+        if self.use_graph and same and getattr(V, "graph", None) is not None:
+            V.graph.launch()
+            z = V.z
+        elif self.use_graph and same and getattr(V, "seen", 0) >= 1 and self._capture is None:
+            g = ops.Graph()
+            g.begin()
+            V.z = emit()
+            g.end()
+            V.graph = g
+            g.launch()
+            z = V.z
         else:
-            ops.rng_fill(V.tape.buf, V.tape.seg_desc, V.tape.seg_scale, len(V.tape.segs), V.tape.total,
-                         self.seed ^ 0x5EED, self.rng_counter)
-        z = self.enc.forward(V.enc, val_spec, None, train=False)
-        out = self.dec.forward(V.dec, z, None, train=False)
-        n = ops.recon_loss_fwd_bwd(val_spec, out, nv, self.L, False, V.lpart, None)
-        ops.loss_finalize(V.lpart, n, 1.0, V.out, 2)
-        ops.rank_loss_fwd_bwd(val_aux, self.n_aux, z, ns, nv, self.n_aux, c["kendall_activation"], V.rank_work,
-                              V.out[1:2], None)
-        n = ops.smooth_loss_fwd_bwd(out, nv, self.L, self.taps, V.lpart, None)
-        ops.loss_finalize(V.lpart, n, 1.0, V.out, 4)
-        z_s = V.tape.view(V.z_sample, nv, ns)
-        out2 = self.dec.forward(V.dec, z_s, None, train=False)
-        z_rec = self.enc.forward(V.enc2, out2, None, train=False)
-        n = ops.mse_fwd_bwd(z_rec, z_s, nv * ns, V.lpart, None)
-        ops.loss_finalize(V.lpart, n, 1.0, V.out, 3)
-        self.disc.forward_backward(V.disc, V.sl_disc, z, V.out[0:1], train=False)
+            z = emit()
+            V.inputs, V.seen, V.graph = (val_spec.data_ptr(), val_aux.data_ptr()), getattr(V, "seen", 0) + 1, None
         v = V.out.cpu().tolist()
         return z, {k: v[i] for k, i in LOSS_SLOTS.items() if k != "mi_accum"}
