@@ -137,29 +137,35 @@ __device__ __forceinline__ void bnbwd_prologue(const double* partials, int npart
 // <= 64) with a halving butterfly: log2(NV) exchange steps that halve the number of live values, then plain
 // xor steps.  Afterwards lane l holds in v[0] the group total of value index group_multi_slot<NV>(l)
 // (NV + log2(width/NV) shuffles instead of NV * log2(width)).
-template <int NV>
-__device__ __forceinline__ void group_multi_sum(double (&v)[NV], int lane, int width) {
-    int half = NV >> 1;
-#pragma unroll
-    for (int o = 1; o < NV; o <<= 1) {
+// (compile-time recursion: with a runtime loop variable for the number of live values the array is indexed
+// dynamically and ends up in scratch memory -- 14 MB of HBM writes per launch of the weight-gradient kernel)
+template <int NV, int N>
+struct MultiSumLevel {
+    static __device__ __forceinline__ void run(double (&v)[NV], int lane) {
+        constexpr int half = N / 2, o = NV / N;
         const bool up = (lane & o) != 0;
 #pragma unroll
-        for (int i = 0; i < NV / 2; ++i) {
-            if (i < half) {
-                const double send = up ? v[i] : v[i + half];
-                const double keep = up ? v[i + half] : v[i];
-                v[i] = keep + __shfl_xor(send, o, 64);
-            }
+        for (int i = 0; i < half; ++i) {
+            const double send = up ? v[i] : v[i + half];
+            const double keep = up ? v[i + half] : v[i];
+            v[i] = keep + __shfl_xor(send, o, 64);
         }
-        half >>= 1;
+        MultiSumLevel<NV, half>::run(v, lane);
     }
+};
+template <int NV>
+struct MultiSumLevel<NV, 1> {
+    static __device__ __forceinline__ void run(double (&)[NV], int) {}
+};
+template <int NV>
+__device__ __forceinline__ void group_multi_sum(double (&v)[NV], int lane, int width) {
+    MultiSumLevel<NV, NV>::run(v, lane);
     for (int o = NV; o < width; o <<= 1) v[0] += __shfl_xor(v[0], o, 64);
 }
 template <int NV>
-__device__ __forceinline__ int group_multi_slot(int lane) {
-    int idx = 0, half = NV >> 1;
-#pragma unroll
-    for (int o = 1; o < NV; o <<= 1) { if (lane & o) idx += half; half >>= 1; }
+__device__ __forceinline__ int group_multi_slot(int lane) {       // bit k of the lane selects the half at level k
+    int idx = 0;
+    for (int o = 1, half = NV >> 1; o < NV; o <<= 1, half >>= 1) if (lane & o) idx += half;
     return idx;
 }
 

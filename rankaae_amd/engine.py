@@ -761,11 +761,11 @@ class StepEngine:
 
     @_on_stream
     def roofline_probe(self, b, peak_gbs, reps=5):
-        """Dominant kernel of this workload (by rocprofv3 share: the multi-task block weight-gradient
-        kernel for ``compact``, fused dense forward for ``FC``): algorithmic bytes per launch / average
+        """Dominant kernel of this workload (by rocprofv3 share: phase A of the fused residual-block forward
+        for ``compact``, fused dense forward for ``FC``): algorithmic bytes per launch / average
         HIP-event duration, over ``reps`` eager steps; plus the same for the largest Conv1d of the
         model run alone at batch 4096, where the launch floor no longer hides the kernel."""
-        kind = "block_wgrad" if self.cfg["ae_form"] == "compact" else "dense_fwd"
+        kind = "block_fwd_a" if self.cfg["ae_form"] == "compact" else "dense_fwd"
         saved_graph, saved_hooks = self.use_graph, (self.phase_hook, self.post_phase_hook)
         self.use_graph = False
         self.set_epoch(self.perm.clone(), float(self.alpha_dev))
@@ -780,7 +780,8 @@ class StepEngine:
         nbytes = [n for *_, n in ev]
         avg_us, avg_bytes = float(np.mean(t_us)), float(np.mean(nbytes))
         ach = avg_bytes / (avg_us * 1e-6) / 1e9
-        out = {"bound": "hbm", "kernel": {"block_wgrad": "wgrad_multi_kernel", "dense_fwd": "dense_fwd_kernel"}[kind],
+        out = {"bound": "hbm", "kernel": {"block_fwd_a": "block_fwd_a_kernel", "block_wgrad": "wgrad_multi_kernel",
+                                          "dense_fwd": "dense_fwd_kernel"}[kind],
                "achieved": round(ach, 2), "peak": peak_gbs, "unit": "GB/s", "frac": round(ach / peak_gbs, 5),
                "traffic": None, "launches_per_step": len(ev) // reps, "avg_launch_us": round(avg_us, 2),
                "algorithmic_bytes_per_launch": int(avg_bytes),

@@ -175,8 +175,15 @@ class CompactNet:
             fused = self.fused and k.Cin <= 8 and k.Cout <= 8
             if fused:
                 # two kernels per block: everything that only needs bn1, then everything that needs bn2 / bn_excit
-                n1 = ops.block_fwd_a(vR(True), self._mask(masks, i, train), b, k, m, w.T1, w.Sh, w.E1, w.E2, w.pT1,
-                                     w.pE2 if k.cve is not None else None)
+                # algorithmic bytes of phase A: the block input (and its dropout mask) read once, T1, Sh,
+                # E1, E2 written once, weights read once
+                mask_i = self._mask(masks, i, train)
+                nbytes = 4 * b * (k.Cin * k.Lin * (2 if mask_i is not None else 1) + k.Cout * k.L1 +
+                                  (k.Cout * k.Lout if k.cvs is not None else 0) + k.Cin * k.E + k.Cin * k.Lout) + \
+                    4 * (m.conv1.weight.numel() + m.fc1.weight.numel() + m.fc2.weight.numel() +
+                         (m.conv_short.weight.numel() if k.cvs is not None else 0))
+                n1 = self.eng.probe_launch("block_fwd_a", nbytes, lambda: ops.block_fwd_a(
+                    vR(True), mask_i, b, k, m, w.T1, w.Sh, w.E1, w.E2, w.pT1, w.pE2 if k.cve is not None else None))
                 w.nT1 = w.nE2 = n1
                 v1 = ops.make_view(w.T1, m.relu1.weight, self._bn(m.bn2, w.pT1, w.nT1, b * k.L1, train, True))
                 if k.cve is not None:
