@@ -95,8 +95,14 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(DenseFwdArgs a) {
         const int k = 4 * q + (lane >> 4);
         wreg[q] = (col < a.N && k < a.K) ? a.w[(size_t)col * a.K + k] : 0.f;
     }
-    if (a.in_kind == RAAE_IN_PRELU_BN_DROP)
-        raae::bn_prologue(a.bn, a.K, s_mean, s_rstd, blockIdx.x == 0 && blockIdx.y == 0);
+    if (a.in_kind == RAAE_IN_PRELU_BN_DROP) {
+        if (a.K <= 64) {            // wave-per-statistic pass (raae_common.h), as in the conv kernels
+            const raae::StatJob jobs[1] = {raae::stat_job_bn(a.bn, a.K, s_mean, s_rstd, true)};
+            raae::stat_jobs<1>(jobs, blockIdx.x == 0 && blockIdx.y == 0);
+        } else {
+            raae::bn_prologue(a.bn, a.K, s_mean, s_rstd, blockIdx.x == 0 && blockIdx.y == 0);
+        }
+    }
     if (a.in_kind != RAAE_IN_NONE)
         for (int k = tid; k < a.K; k += 256) s_slope[k] = a.slope[k];
     __syncthreads();
@@ -175,13 +181,23 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int NT = N16 >> 4, KT = K16 >> 4;
 
-    if (a.g_kind == RAAE_G_PRELU_BN) {
-        raae::bn_prologue(a.out_bn, a.N, o_mean, o_rstd, false);
-        raae::bnbwd_prologue(a.g_partials, a.g_nparts, a.N, a.out_bn.count, m1, m2);
+    const bool g_bn = a.g_kind == RAAE_G_PRELU_BN, i_bn = a.in_kind == RAAE_IN_PRELU_BN_DROP;
+    if ((!g_bn || a.N <= 64) && (!i_bn || a.K <= 64)) {
+        // the three statistic reductions side by side, one wave each (they used to run one after the other)
+        const raae::StatJob jobs[3] = {
+            g_bn ? raae::stat_job_bn(a.out_bn, a.N, o_mean, o_rstd, false) : raae::stat_job_none(),
+            g_bn ? raae::stat_job_bwd(a.g_partials, a.g_nparts, a.N, a.out_bn.count, m1, m2) : raae::stat_job_none(),
+            i_bn ? raae::stat_job_bn(a.bn, a.K, i_mean, i_rstd, false) : raae::stat_job_none()};
+        raae::stat_jobs<3>(jobs, false);
+    } else {
+        if (g_bn) {
+            raae::bn_prologue(a.out_bn, a.N, o_mean, o_rstd, false);
+            raae::bnbwd_prologue(a.g_partials, a.g_nparts, a.N, a.out_bn.count, m1, m2);
+        }
+        if (i_bn) raae::bn_prologue(a.bn, a.K, i_mean, i_rstd, false);
     }
     if (a.g_kind == RAAE_G_PRELU_BN || a.g_kind == RAAE_G_PRELU)
         for (int n = tid; n < a.N; n += 256) o_slope[n] = a.out_slope[n];
-    if (a.in_kind == RAAE_IN_PRELU_BN_DROP) raae::bn_prologue(a.bn, a.K, i_mean, i_rstd, false);
     if (a.in_kind != RAAE_IN_NONE)
         for (int k = tid; k < a.K; k += 256) i_slope[k] = a.slope[k];
     __syncthreads();
