@@ -9,7 +9,7 @@
 // gradients are produced one workgroup per element as final values.
 #ifdef RAAE_STAMPS
 __device__ long long d_stamps[4][3][16];
-__device__ unsigned long long d_stage_sum[4][16], d_stage_cnt[4][16];   // per kernel: ticks spent before stamp i, visits
+__device__ unsigned long long d_stage_sum[4][3][16], d_stage_cnt[4][3][16];   // per kernel: ticks spent before stamp i, visits
 __device__ long long d_stage_prev[4];
 #endif
 #include "raae_common.h"

@@ -30,14 +30,15 @@ for k in range(4):
         base = st[idx[0]]
         print(f"kernel {k} gridclass {g}: " + " ".join(f"[{i}]{(st[i]-base)*0.01:.2f}" for i in idx))
 
-# per-stage totals over all launches of the run (ticks of 10 ns): mean time per visit and share of the kernel
+# per-stage totals over all launches of the run (ticks of 10 ns), per kernel and grid class (<=64, <=128, more
+# workgroups): mean time per launch spent before each stamp
 lib.raae_debug_stage_totals.restype = ctypes.c_int
-ssum = np.zeros((4, 16), dtype=np.uint64); scnt = np.zeros((4, 16), dtype=np.uint64)
+ssum = np.zeros((4, 3, 16), dtype=np.uint64); scnt = np.zeros((4, 3, 16), dtype=np.uint64)
 if lib.raae_debug_stage_totals(ssum.ctypes.data_as(ctypes.c_void_p), scnt.ctypes.data_as(ctypes.c_void_p)) == 0:
     for k in range(4):
-        if scnt[k].sum() == 0:
-            continue
-        tot = float(ssum[k].sum())
-        launches = max(int(scnt[k][1]), 1)
-        print(f"kernel {k}: mean in-kernel {tot * 0.01 / launches:.2f} us over {launches} launches; stage means (us/launch): " +
-              " ".join(f"[{i}]{float(ssum[k][i]) * 0.01 / launches:.2f}" for i in range(1, 16) if scnt[k][i]))
+        for g in range(3):
+            if scnt[k, g].sum() == 0:
+                continue
+            launches = max(int(scnt[k, g][1]), 1)
+            print(f"kernel {k} gridclass {g}: mean in-kernel {float(ssum[k, g].sum()) * 0.01 / launches:.2f} us over {launches} launches; "
+                  "stage means (us/launch): " + " ".join(f"[{i}]{float(ssum[k, g][i]) * 0.01 / launches:.2f}" for i in range(1, 16) if scnt[k, g][i]))
