@@ -13,6 +13,7 @@ __device__ unsigned long long d_stage_sum[4][3][16], d_stage_cnt[4][3][16];   //
 __device__ long long d_stage_prev[4];
 #endif
 #include "raae_common.h"
+#include <string.h>
 #include <stdlib.h>
 
 namespace {
@@ -716,7 +717,20 @@ extern "C" int raae_block_fwd_a(const raae_block_fwd_a_t* in, int* nparts, void*
     if (nparts) *nparts = grid;
     const size_t lds = sizeof(float) * ((size_t)a.S * per + conv_nw(&a.cv1) + (a.has_short ? conv_nw(&a.cvs) : 0) +
                                         (size_t)a.E * a.Lin + (size_t)a.Lout * a.E);
-    hipLaunchKernelGGL(block_fwd_a_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+    int kind = -1;
+    for (int k = 0; k < kNumBlkShapes; ++k) {
+        const BlkShape& b = kBlk[k];
+        if (b.Cin == a.Cin && b.Cout == a.Cout && b.Lin == a.Lin && b.L1 == a.L1 && b.Lout == a.Lout && b.E == a.E &&
+            b.has_short == (a.has_short != 0) && !memcmp(&b.cv1, &a.cv1, sizeof(raae_conv_t)) &&
+            (!a.has_short || !memcmp(&b.cvs, &a.cvs, sizeof(raae_conv_t)))) { kind = k; break; }
+    }
+#define RAAE_LAUNCH_KIND(KERNEL, ...) switch (kind) { \
+        case 0: hipLaunchKernelGGL(KERNEL<0>, __VA_ARGS__); break; case 1: hipLaunchKernelGGL(KERNEL<1>, __VA_ARGS__); break; \
+        case 2: hipLaunchKernelGGL(KERNEL<2>, __VA_ARGS__); break; case 3: hipLaunchKernelGGL(KERNEL<3>, __VA_ARGS__); break; \
+        case 4: hipLaunchKernelGGL(KERNEL<4>, __VA_ARGS__); break; case 5: hipLaunchKernelGGL(KERNEL<5>, __VA_ARGS__); break; \
+        case 6: hipLaunchKernelGGL(KERNEL<6>, __VA_ARGS__); break; default: hipLaunchKernelGGL(KERNEL<-1>, __VA_ARGS__); }
+    static_assert(kNumBlkShapes == 7, "RAAE_LAUNCH_KIND enumerates the shape table");
+    RAAE_LAUNCH_KIND(block_fwd_a_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a)
     RAAE_LAUNCH_RET();
 }
 
