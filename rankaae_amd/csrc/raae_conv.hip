@@ -696,6 +696,35 @@ extern "C" int raae_grad_materialize(const raae_grad_t* go, int B, int C, int L,
     RAAE_LAUNCH_RET();
 }
 
+// ---- shape-specialised instances of the fused block kernels (raae_block_shapes.inc)
+#define RAAE_LAUNCH_KIND(KERNEL, ...) switch (kind) { \
+        case 0: hipLaunchKernelGGL(KERNEL<0>, __VA_ARGS__); break; case 1: hipLaunchKernelGGL(KERNEL<1>, __VA_ARGS__); break; \
+        case 2: hipLaunchKernelGGL(KERNEL<2>, __VA_ARGS__); break; case 3: hipLaunchKernelGGL(KERNEL<3>, __VA_ARGS__); break; \
+        case 4: hipLaunchKernelGGL(KERNEL<4>, __VA_ARGS__); break; case 5: hipLaunchKernelGGL(KERNEL<5>, __VA_ARGS__); break; \
+        case 6: hipLaunchKernelGGL(KERNEL<6>, __VA_ARGS__); break; default: hipLaunchKernelGGL(KERNEL<-1>, __VA_ARGS__); }
+static_assert(kNumBlkShapes == 7, "RAAE_LAUNCH_KIND enumerates the shape table");
+static bool same_conv(const raae_conv_t& x, const raae_conv_t& y) { return !memcmp(&x, &y, sizeof(raae_conv_t)); }
+// phase A kernels see (Cin, Cout, Lin, L1, Lout, E, cv1, cvs); phase B kernels (Cin, Cout, L1, Lout, cv2, cve)
+static int blk_kind_a(int Cin, int Cout, int Lin, int L1, int Lout, int E, const raae_conv_t& cv1, int has_short,
+                      const raae_conv_t& cvs, int has_excit, bool check_excit) {
+    for (int k = 0; k < kNumBlkShapes; ++k) {
+        const BlkShape& b = kBlk[k];
+        if (b.Cin == Cin && b.Cout == Cout && b.Lin == Lin && b.L1 == L1 && b.Lout == Lout && b.E == E &&
+            b.has_short == (has_short != 0) && (!check_excit || b.has_excit == (has_excit != 0)) && same_conv(b.cv1, cv1) &&
+            (!has_short || same_conv(b.cvs, cvs))) return k;
+    }
+    return -1;
+}
+static int blk_kind_b(int Cin, int Cout, int L1, int Lout, const raae_conv_t& cv2, int has_short, int has_excit,
+                      const raae_conv_t& cve) {
+    for (int k = 0; k < kNumBlkShapes; ++k) {
+        const BlkShape& b = kBlk[k];
+        if (b.Cin == Cin && b.Cout == Cout && b.L1 == L1 && b.Lout == Lout && b.has_short == (has_short != 0) &&
+            b.has_excit == (has_excit != 0) && same_conv(b.cv2, cv2) && (!has_excit || same_conv(b.cve, cve))) return k;
+    }
+    return -1;
+}
+
 extern "C" int raae_block_fwd_a(const raae_block_fwd_a_t* in, int* nparts, void* stream) {
     RAAE_CHECK_ARG(in && in->B > 0 && in->Cin >= 1 && in->Cin <= CT_MAXCH && in->Cout >= 1 && in->Cout <= CT_MAXCH);
     RAAE_CHECK_ARG(view_ok(&in->in, in->Cin) && !in->in.mask && conv_ok(&in->cv1) && (!in->has_short || conv_ok(&in->cvs)));
@@ -717,19 +746,7 @@ extern "C" int raae_block_fwd_a(const raae_block_fwd_a_t* in, int* nparts, void*
     if (nparts) *nparts = grid;
     const size_t lds = sizeof(float) * ((size_t)a.S * per + conv_nw(&a.cv1) + (a.has_short ? conv_nw(&a.cvs) : 0) +
                                         (size_t)a.E * a.Lin + (size_t)a.Lout * a.E);
-    int kind = -1;
-    for (int k = 0; k < kNumBlkShapes; ++k) {
-        const BlkShape& b = kBlk[k];
-        if (b.Cin == a.Cin && b.Cout == a.Cout && b.Lin == a.Lin && b.L1 == a.L1 && b.Lout == a.Lout && b.E == a.E &&
-            b.has_short == (a.has_short != 0) && !memcmp(&b.cv1, &a.cv1, sizeof(raae_conv_t)) &&
-            (!a.has_short || !memcmp(&b.cvs, &a.cvs, sizeof(raae_conv_t)))) { kind = k; break; }
-    }
-#define RAAE_LAUNCH_KIND(KERNEL, ...) switch (kind) { \
-        case 0: hipLaunchKernelGGL(KERNEL<0>, __VA_ARGS__); break; case 1: hipLaunchKernelGGL(KERNEL<1>, __VA_ARGS__); break; \
-        case 2: hipLaunchKernelGGL(KERNEL<2>, __VA_ARGS__); break; case 3: hipLaunchKernelGGL(KERNEL<3>, __VA_ARGS__); break; \
-        case 4: hipLaunchKernelGGL(KERNEL<4>, __VA_ARGS__); break; case 5: hipLaunchKernelGGL(KERNEL<5>, __VA_ARGS__); break; \
-        case 6: hipLaunchKernelGGL(KERNEL<6>, __VA_ARGS__); break; default: hipLaunchKernelGGL(KERNEL<-1>, __VA_ARGS__); }
-    static_assert(kNumBlkShapes == 7, "RAAE_LAUNCH_KIND enumerates the shape table");
+    const int kind = blk_kind_a(a.Cin, a.Cout, a.Lin, a.L1, a.Lout, a.E, a.cv1, a.has_short, a.cvs, 0, false);
     RAAE_LAUNCH_KIND(block_fwd_a_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a)
     RAAE_LAUNCH_RET();
 }
@@ -751,7 +768,8 @@ extern "C" int raae_block_fwd_b(const raae_block_fwd_b_t* in, int* nparts, void*
     const int grid = a.ngroups < RAAE_MAX_PARTS ? a.ngroups : RAAE_MAX_PARTS;
     if (nparts) *nparts = grid;
     const size_t lds = sizeof(float) * ((size_t)a.S * per + conv_nw(&a.cv2) + (a.has_excit ? conv_nw(&a.cve) : 0));
-    hipLaunchKernelGGL(block_fwd_b_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+    const int kind = blk_kind_b(a.Cin, a.Cout, a.L1, a.Lout, a.cv2, a.has_short, a.has_excit, a.cve);
+    RAAE_LAUNCH_KIND(block_fwd_b_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a)
     RAAE_LAUNCH_RET();
 }
 
@@ -775,7 +793,8 @@ extern "C" int raae_block_bwd_b(const raae_block_bwd_b_t* in, int* nparts, void*
     const int grid = a.ngroups < 512 ? a.ngroups : 512;
     if (nparts) *nparts = grid;
     const size_t lds = sizeof(float) * ((size_t)a.S * per + conv_nw(&a.cv2) + (a.has_excit ? conv_nw(&a.cve) : 0));
-    hipLaunchKernelGGL(block_bwd_b_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+    const int kind = blk_kind_b(a.Cin, a.Cout, a.L1, a.Lout, a.cv2, a.has_short, a.has_excit, a.cve);
+    RAAE_LAUNCH_KIND(block_bwd_b_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a)
     RAAE_LAUNCH_RET();
 }
 
@@ -801,7 +820,8 @@ extern "C" int raae_block_bwd_a(const raae_block_bwd_a_t* in, int* nparts, void*
     const int grid = a.ngroups < 512 ? a.ngroups : 512;
     if (nparts) *nparts = grid;
     const size_t lds = sizeof(float) * ((size_t)a.S * per + wfl);
-    hipLaunchKernelGGL(block_bwd_a_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+    const int kind = blk_kind_a(a.Cin, a.Cout, a.Lin, a.L1, a.Lout, a.E, a.cv1, a.has_short, a.cvs, a.has_excit, true);
+    RAAE_LAUNCH_KIND(block_bwd_a_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a)
     RAAE_LAUNCH_RET();
 }
 
