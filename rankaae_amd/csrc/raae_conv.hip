@@ -464,6 +464,8 @@ __global__ __launch_bounds__(256) void grad_materialize_kernel(GradMatArgs a) {
     }
 }
 
+#include "raae_block_shapes.inc"     // constexpr table of the residual-block shapes the fused kernels are instantiated for
+__host__ __device__ constexpr int clg2(int v) { int s = -1; if (v > 0 && !(v & (v - 1))) { s = 0; while ((1 << s) < v) ++s; } return s; }
 #include "raae_conv_tiled.inc"
 #include "raae_block_fused.inc"
 #include "raae_conv_strip.inc"
@@ -874,6 +876,21 @@ extern "C" int raae_block_wgrad(const raae_block_wgrad_t* in, int* nslab, void* 
         if (d > dyn) dyn = d;
     }
     m.first[m.ntask] = total;
-    hipLaunchKernelGGL(wgrad_multi_kernel, dim3(total), dim3(256), dyn, (hipStream_t)stream, m);
+    // shape-specialised instance: every conv task must be one of the convs of a known block shape
+    int kind = -1;
+    for (int k = 0; k < kNumBlkShapes && kind < 0; ++k) {
+        const BlkShape& b = kBlk[k];
+        bool all = in->n_conv > 0;
+        for (int i = 0; i < in->n_conv && all; ++i) {
+            const raae_conv_t& cv = in->conv[i].cv;
+            const int w = same_conv(cv, b.cv1) ? 1 : same_conv(cv, b.cv2) ? 2 : (b.has_excit && same_conv(cv, b.cve)) ? 3 :
+                          (b.has_short && same_conv(cv, b.cvs)) ? 4 : 0;
+            m.which[i] = w;
+            all = w != 0;
+        }
+        if (all) kind = k;
+    }
+    if (kind < 0) for (int i = 0; i < 4; ++i) m.which[i] = 0;
+    RAAE_LAUNCH_KIND(wgrad_multi_kernel, dim3(total), dim3(256), dyn, (hipStream_t)stream, m)
     RAAE_LAUNCH_RET();
 }
