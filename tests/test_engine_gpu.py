@@ -45,7 +45,24 @@ PHASE_OF = {"adversarial": "adversarial", "correlation": "kendall", "reconstruct
             "mutual_info": "mutual_info", "smoothness": "smooth"}
 
 
+# Cases without a reference fixture: the oracle (pinned to the reference by tests/test_oracle_golden.py) is the
+# expectation.  nstyle = 5 makes the first decoder block 5 -> 8 channels: not a shape the fused kernels are
+# instantiated for, so their GENERIC instances (and a non-power-of-two channel count) are what runs.
+INLINE_CASES = {
+    "compact_nstyle5": dict(n_rows=420, n_points=256, data_seed=2, model_seed=31,
+                            over=dict(ae_form="compact", nstyle=5, n_aux=3, batch_size=48)),
+}
+
+
 def load_case(case):
+    if case in INLINE_CASES:
+        c = INLINE_CASES[case]
+        with open(os.path.join(os.path.dirname(__file__), "golden", "ref_compact_small.json")) as f:
+            cfg = dict(json.load(f)["config"])
+        cfg.update(c["over"])
+        g = dict(config=cfg, n_rows=c["n_rows"], n_points=c["n_points"], data_seed=c["data_seed"], model_seed=c["model_seed"])
+        spec, aux, _ = make_spectra(g["n_rows"], g["n_points"], cfg["n_aux"], seed=g["data_seed"])
+        return g, cfg, spec, aux
     with open(os.path.join(os.path.dirname(__file__), "golden", f"ref_{case}.json")) as f:
         g = json.load(f)
     cfg = g["config"]
@@ -102,7 +119,7 @@ def _snapshot(tr, name):
 
 
 @pytest.mark.parametrize("case,steps", [("fc_small", (1, 2, 5, 8)), ("fc_adam_nodrop", (1, 3)), ("fc_512_aux12", (2,)),
-                                        ("compact_small", (1, 2, 5, 8))])
+                                        ("compact_small", (1, 2, 5, 8)), ("compact_nstyle5", (1, 3))])
 def test_p2_teacher_forced_steps(case, steps):
     g, cfg, spec, aux = load_case(case)
     torch.set_num_threads(1)
@@ -211,7 +228,7 @@ def test_p2_teacher_forced_steps(case, steps):
                     assert torch.allclose(val.cpu(), sd[key], rtol=1e-4, atol=1e-6), (case, k, key)
 
 
-@pytest.mark.parametrize("case", ["fc_small", "compact_small"])
+@pytest.mark.parametrize("case", ["fc_small", "compact_small", "compact_nstyle5"])
 def test_graph_replay_is_bitwise_eager(case):
     """The captured hipGraph replays the very same program: after 6 steps (3 of them replays, last
     one a ragged batch through a second plan) weights and losses are BITWISE those of eager launches,
