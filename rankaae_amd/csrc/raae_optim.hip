@@ -216,10 +216,10 @@ extern "C" int raae_graph_end(void* stream, void** graph_exec) {
     hipGraph_t graph = nullptr;
     hipError_t e = hipStreamEndCapture((hipStream_t)stream, &graph);
     if (e != hipSuccess) return (int)e;
-    if (const char* dot = getenv("RAAE_GRAPH_DOT")) hipGraphDebugDotPrint(graph, dot, hipGraphDebugDotFlagsVerbose);
+    if (const char* dot = getenv("RAAE_GRAPH_DOT")) (void)hipGraphDebugDotPrint(graph, dot, hipGraphDebugDotFlagsVerbose);
     hipGraphExec_t ex = nullptr;
     e = hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0);
-    hipGraphDestroy(graph);
+    (void)hipGraphDestroy(graph);
     if (e != hipSuccess) return (int)e;
     *graph_exec = (void*)ex;
     return 0;
