@@ -147,12 +147,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # rehearsal on a one-GPU box: RANKAAE_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo (RCCL refuses
+    # two ranks on one device); it exercises sharding, graph segmentation and the collectives, not the speed
+    rehearsal = os.environ.get("RANKAAE_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from rankaae_amd.engine import StepEngine
     from rankaae_amd.synthetic import make_spectra
@@ -167,8 +175,11 @@ def main():
     for kv in args.set:
         k, v = kv.split("=", 1)
         cfg[k] = json.loads(v)
-    spec, aux, _ = make_spectra(args.rows, cfg["dim_in"], cfg["n_aux"], seed=0)
-    n_train = split_counts(args.rows)[0]
+    # weak scaling: the data set grows with the number of ranks, so that every rank runs the same number of
+    # steps per epoch as the single-GPU run (with 7000 rows fixed, 8 ranks would reshuffle every 2 steps)
+    rows = args.rows * world
+    spec, aux, _ = make_spectra(rows, cfg["dim_in"], cfg["n_aux"], seed=0)
+    n_train = split_counts(rows)[0]
     enc, dec, dis = build_models(cfg, 1234)
     eng = StepEngine(enc, dec, dis, cfg, dev, rng_mode="philox", seed=1234 + rank, use_graph=not args.no_graph,
                      world_size=world, rank=rank)
@@ -216,19 +227,21 @@ def main():
             "unit": f"steps/s (five-phase steps on {b}-row batches, summed over ranks)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: {args.rows}x{cfg['dim_in']} synthetic spectra (train split "
+            "config": {"workload": f"BASELINE configs[1]: {rows}x{cfg['dim_in']} synthetic spectra ({args.rows} per GPU; train split "
                                    f"{n_train}), batch {b}/GPU, ae_form={cfg['ae_form']}, nstyle={cfg['nstyle']}, "
                                    f"n_aux={cfg['n_aux']}, AdamW, 5 phases incl. smoothness",
                        "global_batch": b * world, "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
                        "rng": "philox tape (device)"},
             "losses_finite": finite, "last_losses": {k: round(v, 6) for k, v in losses.items()},
         }
-        if not args.no_roofline:
+        # the extras run on ONE GPU only: with several ranks the probe's extra training steps would enter
+        # collectives the other ranks never join, and the contract asks for the CPU baseline at N = 1
+        if not args.no_roofline and world == 1:
             line["roofline"] = eng.roofline_probe(b, HBM_PEAK_GBS)
             line["roofline"]["traffic"] = pmc_traffic(line["roofline"]["kernel"], cfg["ae_form"], b)
         if not args.no_epoch and world == 1:
             line["epoch_inclusive"] = epoch_inclusive(cfg, spec, aux)
-        if args.cpu_budget > 0:
+        if args.cpu_budget > 0 and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg, spec, aux, args.cpu_budget)
             line["speedup_vs_cpu_baseline"] = round(value / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line), flush=True)
