@@ -28,11 +28,13 @@ def full_global_batches(n_rows, world, b):
 
 
 def allreduce_mean_(buf, group=None):
-    """In-place mean over ranks.  SUM + scale rather than ReduceOp.AVG so the identical call works
-    on RCCL and on gloo."""
+    """In-place mean over ranks: ``ReduceOp.AVG`` on RCCL (one kernel), SUM + scale on gloo (which has no AVG)."""
     world = dist.get_world_size(group)
     if world == 1:
         return buf
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-    buf.mul_(1.0 / world)
+    if dist.get_backend(group) == "nccl":
+        dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=group)
+    else:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        buf.mul_(1.0 / world)
     return buf
