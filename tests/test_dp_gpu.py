@@ -11,8 +11,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("case", ["fc_small", "compact_small"])
-def test_dp_path_one_rank_equals_plain(case):
+@pytest.mark.parametrize("case,in_graph", [("fc_small", True), ("compact_small", True), ("compact_small", False)])
+def test_dp_path_one_rank_equals_plain(case, in_graph):
     import torch.distributed as dist
     import test_engine_gpu as T
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -20,6 +20,8 @@ def test_dp_path_one_rank_equals_plain(case):
     if not dist.is_initialized():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     g, cfg, spec, aux = T.load_case(case)
+    cfg = dict(cfg)
+    cfg["in_graph_allreduce"] = in_graph      # own RCCL communicator captured in the graph | graph cut at the collectives
     bs = cfg["batch_size"]
     results = []
     for world in (1, 2):
@@ -44,7 +46,12 @@ def test_dp_path_one_rank_equals_plain(case):
         results.append((eng.arena.P.clone(), eng.losses()))
         if world == 2:
             items = eng.plans[bs].graphs[True]
-            assert sum(1 for it in items if not hasattr(it, "launch")) == 5, "five collectives between graph segments"
+            cuts = sum(1 for it in items if not hasattr(it, "launch"))
+            if in_graph:
+                assert eng.graph_ar is not None, "the in-graph all-reduce failed its self-test on this box"
+                assert cuts == 0 and len(items) == 1, "one graph per step with the five all-reduces inside"
+            else:
+                assert eng.graph_ar is None and cuts == 5, "five collectives between graph segments"
     # stop RCCL's watchdog thread before other tests capture graphs in this process: it polls its events
     # with hipEventQuery, which HIP rejects process-wide while ANY stream is capturing
     dist.destroy_process_group()
