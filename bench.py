@@ -90,7 +90,7 @@ def cpu_baseline(cfg, spec, aux, budget_s):
 
 def epoch_inclusive(cfg, spec, aux, epochs=8):
     """SURVEY 8d asks for train-only AND epoch-inclusive throughput: ``Trainer.train`` with its per-epoch
-    validation forward, five validation losses, Shapiro / Spearman metrics (scipy, host, as the reference) and
+    validation forward, five validation losses, Shapiro / Spearman metrics (raae_style_metrics, on the device) and
     the scheduler step; epochs 3.. are timed (the first two emit and capture the graphs)."""
     import logging
     import tempfile

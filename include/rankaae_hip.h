@@ -105,6 +105,14 @@ long raae_rank_loss_work_bytes(int B, int n_aux);
 int raae_rank_loss_fwd_bwd(const float* d, int ldd, const float* z, int ldz, int B, int n_aux, int activate,
                            void* work, float* loss, float* dz, void* stream);
 
+/* Model-selection metrics of the validation styles (sc/clustering/trainer.py:286-292: scipy.stats.shapiro on
+ * every style column, scipy.stats.spearmanr on every column pair of the host copy), computed where the styles
+ * already are.  z [n][k] styles; a_coef: the n/2 Shapiro-Wilk coefficients for this n (Royston AS R94 with the
+ * AS 111 normal quantile, as scipy 1.15.3 forms them -- the host computes them once per n,
+ * rankaae_amd/metrics.py::shapiro_coefficients); work: 2*k*n doubles (average ranks, sorted columns);
+ * out: k doubles W_c, then k(k-1)/2 doubles rho_(p,q), p < q, in itertools.combinations order. */
+int raae_style_metrics(const float* z, int n, int k, const double* a_coef, double* work, double* out, void* stream);
+
 /* recon_loss (functions.py:81-107): scale!=0 => "flexible target" branch.
  * partial: [>= grid] doubles (fixed-order loss partials); *nparts = grid. dout may be NULL. */
 int raae_recon_loss_fwd_bwd(const float* spec_in, const float* spec_out, int B, int L, int scale,
@@ -326,7 +334,7 @@ int raae_event_destroy(void* ev);
 int raae_stream_sync(void* stream);
 const char* raae_error_string(int code);
 int raae_device_info(int* cu_count, int* lds_bytes, char* name, int name_len);
-#define RAAE_ABI_VERSION 3
+#define RAAE_ABI_VERSION 4
 int raae_abi_version(void);
 /* First 16 hex digits of sha256 over include/rankaae_hip.h + csrc/raae_*.{h,inc,hip} at build time
  * (build.sh); the Python loader recomputes it and refuses a library built from other sources. */

@@ -24,6 +24,7 @@ import torch
 from torch import nn
 
 from . import _lib, ops
+from .metrics import StyleMetrics
 from ._lib import (IN_NONE, IN_PRELU_BN_DROP, IN_PRELU_DROP, OUT_RAW, OUT_STATS_PRELU, OUT_STATS_RAW, OUT_SOFTPLUS,
                    OUT_RELU, G_DIRECT, G_SOFTPLUS, G_PRELU_BN, G_PRELU, G_RELU, RAAE_MAX_PARTS)
 
@@ -922,8 +923,10 @@ class StepEngine:
             V.rank_work = torch.empty(ops.rank_loss_work_bytes(nv, self.n_aux), dtype=torch.uint8, device=dev)
             V.lpart = torch.zeros(RAAE_MAX_PARTS, dtype=torch.float64, device=dev)
             V.out = torch.zeros(8, device=dev)
+            V.metrics = StyleMetrics(nv, ns, dev)
             self.plans[key] = V
         V = self.plans[key]
+        self._val_plan = V
         self.tape = V.tape
         if self.rng_mode == "host":
             torch.empty((), dtype=torch.int64).random_()     # the val DataLoader iterator's _base_seed draw
@@ -947,6 +950,7 @@ class StepEngine:
             n = ops.mse_fwd_bwd(z_rec, z_s, nv * ns, V.lpart, None)
             ops.loss_finalize(V.lpart, n, 1.0, V.out, 3)
             self.disc.forward_backward(V.disc, V.sl_disc, z, V.out[0:1], train=False)
+            V.metrics.launch(z)      # Shapiro-Wilk W per style, Spearman rho per pair (trainer.py:286-292)
             return z
 
         # like the training step: eager once, captured on the second call, replayed afterwards (the inputs must
@@ -968,3 +972,8 @@ class StepEngine:
             V.inputs, V.seen, V.graph = (val_spec.data_ptr(), val_aux.data_ptr()), getattr(V, "seen", 0) + 1, None
         v = V.out.cpu().tolist()
         return z, {k: v[i] for k, i in LOSS_SLOTS.items() if k != "mi_accum"}
+
+    def val_style_metrics(self):
+        """``(W[nstyle], rho[pairs])`` of the styles of the last ``validate`` call (float64 numpy): what the
+        reference's ``shapiro(x).statistic`` / ``spearmanr(a, b).correlation`` return for those columns."""
+        return self._val_plan.metrics.read()

@@ -80,6 +80,11 @@ def rank_loss_fwd_bwd(d, ldd, z, ldz, B, n_aux, activate, work, loss, dz):
           "raae_rank_loss_fwd_bwd")
 
 
+def style_metrics(z, n, k, a_coef, work, out):
+    check(_lib.load().raae_style_metrics(_ptr(z), n, k, _ptr(a_coef, torch.float64), _ptr(work, torch.float64),
+                                         _ptr(out, torch.float64), _stream()), "raae_style_metrics")
+
+
 def recon_loss_fwd_bwd(spec_in, spec_out, B, L, scale, partial, dout):
     n = C.c_int(0)
     check(_lib.load().raae_recon_loss_fwd_bwd(_ptr(spec_in), _ptr(spec_out), B, L, 1 if scale else 0,

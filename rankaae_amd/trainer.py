@@ -12,7 +12,6 @@ Build-only config keys (all optional, defaults preserve reference behaviour):
   ``seed``      Philox seed (``rng_mode: philox``)
 """
 import copy
-import itertools
 import logging
 import os
 import shutil
@@ -107,7 +106,6 @@ class Trainer:
         return out
 
     def train(self, callback=None):
-        from scipy.stats import shapiro, spearmanr
         eng = self.engine
         best_combined_metric = 10.0
         chkpt_dir = f"{self.work_dir}/checkpoints"
@@ -141,11 +139,12 @@ class Trainer:
                     f"{tl['smooth']:.6f},\t{vl['smooth']:.6f},\t"
                     f"{tl['mutual_info']:.6f},\t{vl['mutual_info']:.6f},\t")
             avg_mutual_info = tl["mi_accum"] / n_batch
-            style_np = z.detach().cpu().numpy().T
-            style_shapiro = [shapiro(x).statistic for x in style_np]
-            style_coupling = np.max(np.fabs([spearmanr(style_np[j1], style_np[j2]).correlation
-                                             for j1, j2 in itertools.combinations(range(style_np.shape[0]), 2)]))
-            metrics = [min(style_shapiro), vl["recon"], avg_mutual_info, style_coupling, vl["kendall"]]
+            # shapiro(x).statistic per style / spearmanr(.).correlation per pair of the reference
+            # (trainer.py:286-292), formed on the device by raae_style_metrics
+            style_shapiro, style_rho = eng.val_style_metrics()
+            style_coupling = np.max(np.fabs(style_rho))
+            metrics = [float(np.min(style_shapiro)), vl["recon"], avg_mutual_info, float(style_coupling),
+                       vl["kendall"]]
             combined_metric = -(np.array(self.metric_weights) * np.array(metrics)).sum()
             if combined_metric > best_combined_metric:
                 best_combined_metric = combined_metric

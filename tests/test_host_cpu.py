@@ -147,3 +147,25 @@ def test_data_parallel_sharding_and_gradient_mean_gloo():
         assert p.exitcode == 0
     nb, ok_cover, ok_mean = out.get(timeout=10)
     assert nb == 6 and ok_cover and ok_mean
+
+
+@pytest.mark.parametrize("n", [3, 4, 5, 6, 11, 36, 1050, 1051, 4999])
+def test_shapiro_coefficients_reproduce_scipy_W(n):
+    """The host-built coefficient vector of ``raae_style_metrics`` (AS R94 + AS 111) is scipy's: W formed from
+    it with AS R94's arithmetic equals ``scipy.stats.shapiro(x).statistic`` (public API) to rounding."""
+    from scipy.stats import shapiro
+    from rankaae_amd.metrics import shapiro_coefficients
+    a = shapiro_coefficients(n)
+    assert a.shape == (n // 2,)
+    rng = np.random.default_rng(n)
+    for x in (rng.standard_normal(n).astype(np.float32), rng.exponential(size=n).astype(np.float32)):
+        y = np.sort(x.astype(np.float64)) - np.float64(x[n // 2])
+        coef = np.zeros(n)
+        coef[:n // 2] = -a
+        coef[n - n // 2:] = a[::-1]
+        u = y / (y[-1] - y[0])
+        asa, xsx = coef - coef.sum() / n, u - u.sum() / n
+        ssa, ssx, sax = (asa * asa).sum(), (xsx * xsx).sum(), (asa * xsx).sum()
+        s = np.sqrt(ssa * ssx)
+        w = 1.0 - (s - sax) * (s + sax) / (ssa * ssx)
+        assert abs(w - shapiro(x).statistic) < 1e-13, (n, w, shapiro(x).statistic)

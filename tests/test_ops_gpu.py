@@ -561,3 +561,29 @@ def test_sum3_and_grad_materialize():
     acc = torch.ones(B, Cc, L, device=DEV)
     ops.grad_materialize(goI, B, Cc, L, acc, True, None, 0)
     close(acc, Y.grad + 1.0, 2e-4, 2e-5, "identity shortcut gradient")
+
+
+@pytest.mark.parametrize("n,k", [(1050, 6), (37, 3), (3, 2), (4100, 13), (20000, 2)])
+def test_style_metrics_match_scipy(n, k):
+    """raae_style_metrics == scipy.stats.shapiro / spearmanr (what the reference calls on the host copy of the
+    validation styles, trainer.py:286-292), including tied values, to 1e-12 (f64 sums in another order)."""
+    import itertools
+    from scipy.stats import shapiro, spearmanr
+    from rankaae_amd.metrics import StyleMetrics
+    rng = np.random.default_rng(n + k)
+    z = rng.standard_normal((n, k)).astype(np.float32)
+    z[:, 0] += 0.5 * z[:, k - 1]                              # a correlated pair
+    if n > 3:
+        z[:, 1] = np.round(z[:, 1] * 4) / 4                   # heavy ties
+        z[::7, k - 1] = z[0, k - 1]                           # a run of equal values
+    m = StyleMetrics(n, k, DEV)
+    m.launch(dev(torch.from_numpy(z)))
+    W, rho = m.read()
+    W_ref = np.array([shapiro(z[:, c]).statistic for c in range(k)])
+    rho_ref = np.array([spearmanr(z[:, p], z[:, q]).correlation for p, q in itertools.combinations(range(k), 2)])
+    assert W.shape == W_ref.shape and rho.shape == rho_ref.shape
+    assert np.abs(W - W_ref).max() < 1e-12, (W, W_ref)
+    assert np.abs(rho - rho_ref).max() < 1e-12, (rho, rho_ref)
+    m.launch(dev(torch.from_numpy(z)))                        # fixed-order sums: bitwise repeatable
+    W2, rho2 = m.read()
+    assert np.array_equal(W, W2) and np.array_equal(rho, rho2)

@@ -69,6 +69,14 @@ def test_trainer_end_to_end(case, rng_mode, tmp_path):
     with torch.no_grad():
         z_ref = enc(val_spec)
     assert torch.allclose(z_hip.cpu(), z_ref, rtol=1e-3, atol=1e-4)
+    # the model-selection metrics formed on the device are scipy's on the same styles (trainer.py:286-292)
+    import itertools
+    from scipy.stats import shapiro, spearmanr
+    W, rho = tr.engine.val_style_metrics()
+    zc = z_hip.cpu().numpy().T
+    assert np.allclose(W, [shapiro(x).statistic for x in zc], rtol=0, atol=1e-12)
+    assert np.allclose(rho, [spearmanr(zc[a], zc[b]).correlation
+                             for a, b in itertools.combinations(range(len(zc)), 2)], rtol=0, atol=1e-12)
 
 
 @pytest.mark.parametrize("case", ["p3_fc", "p3_compact"])
