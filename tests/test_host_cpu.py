@@ -169,3 +169,32 @@ def test_shapiro_coefficients_reproduce_scipy_W(n):
         s = np.sqrt(ssa * ssx)
         w = 1.0 - (s - sax) * (s + sax) / (ssa * ssx)
         assert abs(w - shapiro(x).statistic) < 1e-13, (n, w, shapiro(x).statistic)
+
+
+def test_csv_binary_cache_is_transparent(tmp_path):
+    """the second load of a CSV comes from ``<csv>.raae_cache.npz`` with identical arrays and
+    index; touching the CSV invalidates it."""
+    from rankaae_amd import dataloader as dl
+    spec, aux, grid = make_spectra(60, 32, 3, seed=3)
+    csv = str(tmp_path / "d.csv")
+    write_csv(csv, spec, aux, grid)
+    a = dl.load_csv(csv, 3)
+    assert os.path.exists(csv + dl.CACHE_SUFFIX)
+    calls = []
+    orig = dl._parse_csv
+    dl._parse_csv = lambda *k: (calls.append(1), orig(*k))[1]
+    try:
+        b = dl.load_csv(csv, 3)
+        assert not calls                                   # served from the cache
+        ref = orig(csv, 3)
+        for x, y, r in zip(a[:3], b[:3], ref[:3]):
+            assert x.dtype == y.dtype == r.dtype == np.float64
+            assert np.array_equal(x, y) and np.array_equal(x, r)
+        assert list(a[3]) == list(b[3]) == list(ref[3])
+        dl.load_csv(csv, 3, cache=False)
+        assert len(calls) == 1
+        os.utime(csv, ns=(1, 1))                           # a changed CSV must be parsed again
+        dl.load_csv(csv, 3)
+        assert len(calls) == 2
+    finally:
+        dl._parse_csv = orig
