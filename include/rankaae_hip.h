@@ -113,6 +113,10 @@ int raae_rank_loss_fwd_bwd(const float* d, int ldd, const float* z, int ldz, int
  * out: k doubles W_c, then k(k-1)/2 doubles rho_(p,q), p < q, in itertools.combinations order. */
 int raae_style_metrics(const float* z, int n, int k, const double* a_coef, double* work, double* out, void* stream);
 
+/* out[g][l] = mean over s of x[g][s][l], x [groups][per][L]: the n_sampling average of the report's decoder
+ * sweeps (sc/report/analysis.py:78-86, `decoder(con_c).reshape(n_spec, n_sampling, L).mean(axis=1)`). */
+int raae_group_mean(const float* x, int groups, int per, int L, float* out, void* stream);
+
 /* recon_loss (functions.py:81-107): scale!=0 => "flexible target" branch.
  * partial: [>= grid] doubles (fixed-order loss partials); *nparts = grid. dout may be NULL. */
 int raae_recon_loss_fwd_bwd(const float* spec_in, const float* spec_out, int B, int L, int scale,

@@ -117,6 +117,7 @@ SIGNATURES = {
     "raae_rank_loss_work_bytes": (_L, [_I, _I]),
     "raae_rank_loss_fwd_bwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "raae_style_metrics": (_I, [_P, _I, _I, _P, _P, _P, _P]),
+    "raae_group_mean": (_I, [_P, _I, _I, _I, _P, _P]),
     "raae_recon_loss_fwd_bwd": (_I, [_P, _P, _I, _I, _I, _P, _PI, _P, _P]),
     "raae_smooth_loss_fwd_bwd": (_I, [_P, _I, _I, C.POINTER(C.c_float), _I, _P, _PI, _P, _P]),
     "raae_mse_fwd_bwd": (_I, [_P, _P, _L, _P, _PI, _P, _P]),

@@ -127,7 +127,29 @@ __global__ __launch_bounds__(256) void style_stat_kernel(const double* __restric
     }
 }
 
+// out[g][l] = mean_s x[g][s][l]: the n_sampling average of the report's decoder sweeps (sc/report/analysis.py:78-86).
+// One thread per output column element; the sum runs in sample order in double.
+__global__ __launch_bounds__(256) void group_mean_kernel(const float* __restrict__ x, int groups, int per, int L,
+                                                         float* __restrict__ out) {
+    const long n = (long)groups * L;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long g = i / L, l = i - g * L;
+        const float* p = x + g * (long)per * L + l;
+        double acc = 0.0;
+        for (int s = 0; s < per; ++s) acc += (double)p[(long)s * L];
+        out[i] = (float)(acc / (double)per);
+    }
+}
+
 }  // namespace
+
+extern "C" int raae_group_mean(const float* x, int groups, int per, int L, float* out, void* stream) {
+    RAAE_CHECK_ARG(x && out && groups > 0 && per > 0 && L > 0);
+    const long n = (long)groups * L;
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(group_mean_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, groups, per, L, out);
+    RAAE_LAUNCH_RET();
+}
 
 extern "C" int raae_style_metrics(const float* z, int n, int k, const double* a_coef, double* work, double* out,
                                   void* stream) {

@@ -346,6 +346,23 @@ def _on_stream(fn):
     return wrapper
 
 
+def _on_stream_io(fn):
+    """Like ``_on_stream`` for methods that take and return caller tensors: the engine's stream first waits for
+    the caller's current stream (inputs written there) and the caller's stream then waits for the engine's
+    (results read there) -- stream-ordered, no host synchronisation."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *a, **kw):
+        caller = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(caller)
+        with torch.cuda.stream(self.stream):
+            out = fn(self, *a, **kw)
+        caller.wait_stream(self.stream)
+        return out
+    return wrapper
+
+
 class StepPlan:
     """Everything that depends on the batch size: workspaces, tape slots, captured graphs."""
     pass
@@ -836,7 +853,7 @@ class StepEngine:
                 "batch": B, "avg_launch_us": round(us, 2), "algorithmic_bytes": nbytes,
                 "achieved": round(ach, 1), "unit": "GB/s", "frac": round(ach / peak_gbs, 4)}
 
-    @_on_stream
+    @_on_stream_io
     def reconstruct(self, spec):
         """Eval-mode ``styles = Encoder(spec)``, ``spec_out = Decoder(styles)`` for ``[n, L]`` device rows --
         the latent-space export of the reference's report tool (sc/report/analysis_new.py:94-129)."""
@@ -850,6 +867,25 @@ class StepEngine:
         z = self.enc.forward(R.enc, spec, None, train=False)
         out = self.dec.forward(R.dec, z, None, train=False)
         return z.clone(), out.clone()
+
+    @_on_stream_io
+    def decode(self, styles, n_sampling=1):
+        """Eval-mode ``Decoder(styles)`` for ``[n, nstyle]`` device rows; with ``n_sampling > 1`` the rows are
+        ``[n / n_sampling][n_sampling]`` and the mean spectrum of each group is returned -- the decoder sweeps of
+        the reference's report (sc/report/analysis.py:68-86)."""
+        n = styles.shape[0]
+        assert styles.shape[1] == self.nstyle and n % n_sampling == 0
+        key = ("decode", n)
+        if key not in self.plans:
+            R = StepPlan()
+            R.dec = self.dec.alloc(n)
+            self.plans[key] = R
+        out = self.dec.forward(self.plans[key].dec, styles.contiguous(), None, train=False)
+        if n_sampling == 1:
+            return out.clone()
+        mean = torch.empty(n // n_sampling, self.L, device=self.device)
+        ops.group_mean(out, n // n_sampling, n_sampling, self.L, mean)
+        return mean
 
     def phase_gradient(self, P, name):
         """Flat gradient (fixed-order slab sum) of optimizer ``name``'s arena range -- what the

@@ -37,3 +37,25 @@ class Reconstruct:
         np.savetxt(file_path + "_spec_in" + ".txt", self.result["input"])
         np.savetxt(file_path + "_spec_out" + ".txt", self.result["output"])
         np.savetxt(file_path + "_styles" + ".txt", self.result["styles"])
+
+
+def spectra_variation(model, istyle, styles, n_spec=50, n_sampling=1000):
+    """The numbers behind the report's style-variation plots (``plot_spectra_variation``,
+    sc/report/analysis.py:33-86): style ``istyle`` swept over the 5th..95th percentile of its column in
+    ``styles`` in ``n_spec`` steps; with ``n_sampling == 0`` the other styles are 0, otherwise each point is the
+    mean decoded spectrum over ``n_sampling`` draws of the other styles from N(0, 1).  The decoder and the
+    averaging run on the HIP engine.  Returns ``(style_variation[n_spec], spec_out[n_spec, L])`` as numpy."""
+    eng = getattr(model, "engine", model)
+    styles = np.asarray(styles)
+    assert styles.ndim == 2 and styles.shape[1] == eng.nstyle
+    left, right = np.percentile(styles[:, istyle], [5, 95])
+    if n_sampling == 0:
+        c = np.linspace(left, right, n_spec)
+        con_c = torch.zeros(n_spec, eng.nstyle)
+        con_c[:, istyle] = torch.tensor(c, dtype=torch.float)
+        return c, eng.decode(con_c.to(eng.device)).cpu().numpy()
+    con_c = torch.randn([n_spec, n_sampling, eng.nstyle], device=eng.device)
+    variation = torch.linspace(left, right, n_spec, device=eng.device)
+    con_c[..., istyle] = variation[:, None]
+    spec_out = eng.decode(con_c.reshape(n_spec * n_sampling, eng.nstyle), n_sampling=n_sampling)
+    return variation.cpu().numpy(), spec_out.cpu().numpy()

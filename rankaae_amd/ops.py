@@ -85,6 +85,10 @@ def style_metrics(z, n, k, a_coef, work, out):
                                          _ptr(out, torch.float64), _stream()), "raae_style_metrics")
 
 
+def group_mean(x, groups, per, L, out):
+    check(_lib.load().raae_group_mean(_ptr(x), groups, per, L, _ptr(out), _stream()), "raae_group_mean")
+
+
 def recon_loss_fwd_bwd(spec_in, spec_out, B, L, scale, partial, dout):
     n = C.c_int(0)
     check(_lib.load().raae_recon_loss_fwd_bwd(_ptr(spec_in), _ptr(spec_out), B, L, 1 if scale else 0,

@@ -162,3 +162,44 @@ def test_latent_export_matches_exported_modules(tmp_path):
     assert np.allclose(styles, z.numpy(), rtol=1e-3, atol=1e-4)
     assert np.allclose(spec_out, y.numpy(), rtol=1e-3, atol=1e-4)
     assert np.array_equal(res["styles"], styles.astype(np.float32))
+
+
+def test_decoder_sweeps_match_exported_decoder(tmp_path):
+    """``spectra_variation`` (the numbers of the report's ``plot_spectra_variation``, sc/report/analysis.py:33-86)
+    on the HIP engine against the saved plain-PyTorch decoder: exact construction for ``n_sampling == 0``; for
+    ``n_sampling > 0`` the same draws are decoded by both (the generator is re-seeded)."""
+    import logging
+    from rankaae_amd.export import spectra_variation
+    from rankaae_amd.parameter import Parameters
+    from rankaae_amd.trainer import Trainer
+    with open(os.path.join(os.path.dirname(__file__), "golden", "ref_compact_small.json")) as f:
+        g = json.load(f)
+    cfg = dict(g["config"])
+    cfg.update(rng_mode="philox", seed=3, max_epoch=1)
+    spec, aux, _ = make_spectra(g["n_rows"], g["n_points"], cfg["n_aux"], seed=g["data_seed"])
+    quiet = logging.getLogger("sweep_quiet")
+    quiet.addHandler(logging.NullHandler())
+    quiet.propagate = False
+    torch.manual_seed(7)
+    tr = Trainer.from_data(None, igpu=0, verbose=False, work_dir=str(tmp_path), config_parameters=Parameters(cfg),
+                           logger=quiet, loss_logger=quiet, arrays=(spec, aux))
+    tr.train()
+    dec = torch.load(os.path.join(str(tmp_path), "final.pt"), map_location="cpu", weights_only=False)["Decoder"].eval()
+    ns = cfg["nstyle"]
+    styles = np.random.default_rng(0).standard_normal((300, ns))
+    left, right = np.percentile(styles[:, 1], [5, 95])
+    c, out = spectra_variation(tr, 1, styles, n_spec=20, n_sampling=0)
+    assert np.allclose(c, np.linspace(left, right, 20)) and out.shape == (20, cfg["dim_out"])
+    con = torch.zeros(20, ns)
+    con[:, 1] = torch.tensor(c, dtype=torch.float)
+    with torch.no_grad():
+        ref = dec(con).reshape(20, -1).numpy()
+    assert np.allclose(out, ref, rtol=1e-3, atol=1e-4)
+    torch.cuda.manual_seed(11)
+    v, out = spectra_variation(tr, 2, styles, n_spec=7, n_sampling=33)
+    torch.cuda.manual_seed(11)
+    con = torch.randn([7, 33, ns], device=tr.device)
+    con[..., 2] = torch.linspace(*np.percentile(styles[:, 2], [5, 95]), 7, device=tr.device)[:, None]
+    with torch.no_grad():
+        ref = dec(con.reshape(7 * 33, ns).cpu()).reshape(7, 33, -1).mean(axis=1).numpy()
+    assert out.shape == (7, cfg["dim_out"]) and np.allclose(out, ref, rtol=1e-3, atol=1e-4)
