@@ -727,6 +727,10 @@ class StepEngine:
     @_on_stream
     def step(self, b, smooth=True):
         """Run one training step on the next ``b`` rows of the epoch permutation."""
+        if b < 2:
+            # a one-row last batch: the reference's training-mode BatchNorm1d(nstyle) raises exactly this
+            raise ValueError("Expected more than 1 value per channel when training, got input size "
+                             f"torch.Size([{b}, {self.nstyle}])")
         P = self.plan(b)
         stride = self.cursor_stride if self.cursor_stride is not None else b
         if self._host_cursor + b > len(self.train_spec):

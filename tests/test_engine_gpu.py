@@ -251,3 +251,16 @@ def test_graph_replay_is_bitwise_eager(case):
         assert torch.equal(results[0][2], other[2])
         assert results[0][1] == other[1]
     assert all(np.isfinite(v) for v in results[0][1].values())
+
+
+def test_one_row_batch_raises_like_the_reference():
+    """A last batch of ONE row: the reference's training-mode ``BatchNorm1d(nstyle)`` raises ``ValueError``
+    ("Expected more than 1 value per channel when training"); so does the engine, before any launch.  Two rows
+    (the smallest legal batch) step fine."""
+    g, cfg, spec, aux = load_case("compact_small")
+    eng = build_engine(cfg, g["model_seed"], spec, aux)
+    eng.set_epoch(ref_train.epoch_permutation(len(eng.train_spec)), 0.0)
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel when training"):
+        eng.step(1)
+    eng.step(2)
+    assert all(np.isfinite(v) for v in eng.losses().values())
