@@ -2,9 +2,11 @@
 """``train_sc -c <config.yaml> [-w <work_dir>]`` -- same command line, per-trial directory layout
 and log files as the reference's ``sc/cmd/train_sc.py:105-157`` (``training/job_<k>/{messages.txt,
 losses.csv,final.pt}``, ``main_process_message.txt``), with the training itself on the MI355X HIP
-engine.  The ipyparallel engine farm is gone: trials run back to back on this process's GPU, and
-when launched under ``torch.distributed.run`` (WORLD_SIZE > 1) every trial trains data-parallel
-over RCCL (``rankaae_amd.parallel``)."""
+engine.  The ipyparallel engine farm (``train_sc.py:19-45``) becomes one worker process per visible GPU:
+trial ``k`` runs on worker ``k mod n`` (``RANKAAE_TRIAL_WORKERS`` overrides ``n``; on ONE GPU trials run back
+to back, because processes sharing a GPU only time-slice it -- DESIGN.md section 8).  When launched under
+``torch.distributed.run`` (WORLD_SIZE > 1) every trial instead trains data-parallel over RCCL
+(``rankaae_amd.parallel``)."""
 import argparse
 import logging
 import os
@@ -46,6 +48,37 @@ def run_training(job_number, work_dir, train_config, verbose, data_file, timeout
     return metrics, time_used
 
 
+def assign_trials(trials, nworkers):
+    """Trial numbers of each worker: round-robin, like the reference's ipyparallel ``map_sync`` over engines that
+    were given GPU ``id % ngpus`` (``train_sc.py:32-41``)."""
+    return [list(range(w, trials, nworkers)) for w in range(nworkers)]
+
+
+def _trial_worker(worker, jobs, work_dir, config_dict, verbose, data_file, timeout):
+    # a spawned process: nothing has touched the GPU yet; LOCAL_RANK picks it in run_training
+    os.environ["LOCAL_RANK"] = str(worker)
+    cfg = Parameters(config_dict)
+    return [(k,) + tuple(run_training(k, work_dir, cfg, verbose, data_file, timeout)) for k in jobs]
+
+
+def run_trials(trials, work_dir, train_config, verbose, data_file, timeout, logger):
+    """All trials; returns ``[(metrics, time_used)]`` in trial order and the number of worker processes."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    nworkers = 1
+    if world == 1 and trials > 1:
+        # device_count() does not initialise the GPU, so the workers can still be spawned after it
+        nworkers = int(os.environ.get("RANKAAE_TRIAL_WORKERS", torch.cuda.device_count()))
+        nworkers = max(1, min(nworkers, trials))
+    if nworkers == 1:
+        return [run_training(k, work_dir, train_config, verbose, data_file, timeout, logger) for k in range(trials)], 1
+    import multiprocessing as mp
+    with mp.get_context("spawn").Pool(nworkers) as pool:
+        parts = pool.starmap(_trial_worker, [(w, jobs, work_dir, train_config.to_dict(), verbose, data_file, timeout)
+                                             for w, jobs in enumerate(assign_trials(trials, nworkers))])
+    done = sorted(r for part in parts for r in part)
+    return [(m, t) for _, m, t in done], nworkers
+
+
 def main():
     parser = argparse.ArgumentParser()
     parser.add_argument("-c", "--config", type=str, required=True, help="Config for training parameter in YAML format")
@@ -60,9 +93,9 @@ def main():
     timeout = train_config.get("timeout", 10)
     logger = create_logger("Main training:", f"{work_dir}/main_process_message.txt", append=True)
     logger.info("START")
-    logger.info("Running with {} process(es).".format(int(os.environ.get("WORLD_SIZE", "1"))))
     start = time.time()
-    result = [run_training(k, work_dir, train_config, verbose, data_file, timeout, logger) for k in range(trials)]
+    result, nworkers = run_trials(trials, work_dir, train_config, verbose, data_file, timeout, logger)
+    logger.info("Running with {} process(es).".format(max(nworkers, int(os.environ.get("WORLD_SIZE", "1")))))
     time_trials = np.array([r[1] for r in result])
     logger.info(f"Time used for each trial: {time_trials.mean():.2f} +/- {time_trials.std():.2f}s.\n" +
                 " ".join([f"{t:.2f}s" for t in time_trials]))

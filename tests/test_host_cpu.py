@@ -198,3 +198,10 @@ def test_csv_binary_cache_is_transparent(tmp_path):
         assert len(calls) == 2
     finally:
         dl._parse_csv = orig
+
+
+def test_trial_assignment_round_robin():
+    from rankaae_amd.cmd.train_sc import assign_trials
+    assert assign_trials(5, 2) == [[0, 2, 4], [1, 3]]
+    assert assign_trials(3, 8)[:3] == [[0], [1], [2]] and all(not j for j in assign_trials(3, 8)[3:])
+    assert sorted(k for part in assign_trials(32, 8) for k in part) == list(range(32))

@@ -203,3 +203,39 @@ def test_decoder_sweeps_match_exported_decoder(tmp_path):
     with torch.no_grad():
         ref = dec(con.reshape(7 * 33, ns).cpu()).reshape(7, 33, -1).mean(axis=1).numpy()
     assert out.shape == (7, cfg["dim_out"]) and np.allclose(out, ref, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("workers", [1, 2])
+def test_train_sc_command_line_and_trial_workers(workers, tmp_path):
+    """``train_sc -c cfg.yaml -w dir`` (sc/cmd/train_sc.py:105-157): two trials, sequential and through the
+    per-GPU worker processes (both workers share this box's one GPU), leave the reference's directory layout."""
+    import subprocess
+    import sys
+    import yaml
+    with open(os.path.join(os.path.dirname(__file__), "golden", "ref_compact_small.json")) as f:
+        g = json.load(f)
+    cfg = dict(g["config"])
+    cfg.update(max_epoch=2, trials=2, data_file="data.csv", verbose=False, timeout=1)
+    spec, aux, grid = make_spectra(g["n_rows"], g["n_points"], cfg["n_aux"], seed=g["data_seed"])
+    write_csv(str(tmp_path / "data.csv"), spec, aux, grid)
+    with open(tmp_path / "cfg.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    env = dict(os.environ, RANKAAE_TRIAL_WORKERS=str(workers),
+               PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "rankaae_amd.cmd.train_sc", "-c", "cfg.yaml", "-w", str(tmp_path)],
+                       env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    main_log = (tmp_path / "main_process_message.txt").read_text()
+    assert "START" in main_log and "END" in main_log and f"Running with {workers} process(es)." in main_log
+    assert "for 2 trails" in main_log
+    for k in (1, 2):
+        job = tmp_path / "training" / f"job_{k}"
+        # (best.pt appears only when the combined metric beats the reference's initial guess of 10.0)
+        for name in ("messages.txt", "losses.csv", "final.pt", "checkpoints"):
+            assert (job / name).exists(), (k, name)
+        assert (job / "losses.csv").read_text().startswith("Epoch,Train_D,Val_D")
+        assert "Training finished" in (job / "messages.txt").read_text()
+        model = torch.load(job / "final.pt", map_location="cpu", weights_only=False)
+        assert set(model) == {"Encoder", "Decoder", "Style Discriminator"}
