@@ -832,7 +832,7 @@ static const int kWgradTaskGrid = 128;
 extern "C" int raae_block_wgrad(const raae_block_wgrad_t* in, int* nslab, void* stream) {
     RAAE_CHECK_ARG(in && nslab && in->B > 0 && in->n_conv >= 0 && in->n_conv <= 4 && in->n_lin >= 0 && in->n_lin <= 2 &&
                    in->n_conv + in->n_lin > 0);
-    static WgradMultiArgs m;          // large (kernarg by value); host-only scratch, filled per call
+    static thread_local WgradMultiArgs m;   // large (kernarg by value); per-thread host scratch, filled per call
     m.ntask = 0;
     int total = 0;
     size_t dyn = 0;
