@@ -95,7 +95,7 @@ def mutual_info_loss(spec_in, styles, encoder, decoder):
 def smoothness_loss(spec_out, gs_kernel_size=17):
     """``sc/utils/functions.py:194-212`` + ``GaussianSmoothing`` (``model.py:177-229``):
     replicate-pad, 17-tap normalised Gaussian (sigma 3), MSE(x, smoothed x)."""
-    w = gaussian_taps(gs_kernel_size, 3.0).view(1, 1, -1)
+    w = gaussian_taps(gs_kernel_size, 3.0).view(1, 1, -1).to(spec_out.dtype)   # fp32 taps (a no-op for fp32 input)
     pad = (gs_kernel_size - 1) // 2
     padded = F.pad(spec_out.unsqueeze(1), (pad, pad), mode="replicate")
     smoothed = F.conv1d(padded, w, groups=1).squeeze(1)

@@ -18,11 +18,17 @@ P2  teacher-forced, at PHASE granularity: the oracle's state (weights, BN statis
     When the tight comparison fails we therefore require instead (a) styles within 5e-4 of the
     oracle's and (b) the HIP loss == the oracle's loss function evaluated on the HIP styles
     (rel 1e-5), and compare that phase's gradients at 2e-2.
+    At BASELINE configs[2]'s batch (4096 rows; cases ``*_b4096``) the reference's fp32 batch reductions are
+    themselves 0.5-1 % away from exact arithmetic on the cancelling gradients (adversarial and smoothness
+    phases), and the kernels here sum in another order: a tensor that misses 5e-3 there is judged against a
+    FLOAT64 repeat of the same oracle step (same parameters, inputs and replayed random tensors,
+    ``oracle_float64_gradients``): HIP's distance from it must be within 3x the reference-fp32 distance.
     The Adam update itself is pinned to torch.optim in tests/test_ops_gpu.py.
 Free-running K-step equality is NOT tested: the trajectory is chaotic (SURVEY finding 8).
 The engine runs in ``rng_mode="host"``: its tape is drawn from the global torch CPU
 generator in the reference's order, which is itself part of what these tests verify.
 """
+import copy
 import json
 import os
 
@@ -51,6 +57,12 @@ PHASE_OF = {"adversarial": "adversarial", "correlation": "kendall", "reconstruct
 INLINE_CASES = {
     "compact_nstyle5": dict(n_rows=420, n_points=256, data_seed=2, model_seed=31,
                             over=dict(ae_form="compact", nstyle=5, n_aux=3, batch_size=48)),
+    # BASELINE configs[2]'s batch (4096 rows): the HBM-bound regime -- strip convolution kernel, 512-workgroup
+    # grids, hundreds of gradient slabs per parameter, Adam's lane-split slab sum.
+    "compact_b4096": dict(n_rows=6000, n_points=256, data_seed=4, model_seed=41,
+                          over=dict(ae_form="compact", batch_size=4096)),
+    "fc_b4096": dict(n_rows=6000, n_points=256, data_seed=4, model_seed=42,
+                     over=dict(ae_form="FC", batch_size=4096)),
 }
 
 
@@ -118,8 +130,83 @@ def _snapshot(tr, name):
             "lr": [grp["lr"] for grp in tr.optimizers[name].param_groups]}
 
 
+class RandomTape:
+    """Records the random tensors of one fp32 oracle step (``randn``, ``randn_like``, dropout keep-masks) and
+    replays them, cast to the caller's dtype, in a second run -- so that the same step can be repeated in
+    float64 as an arbiter between two fp32 implementations."""
+
+    def __init__(self):
+        import torch.nn.functional as F
+        self.F, self.items, self.pos, self.replay = F, [], 0, False
+        self._randn, self._randn_like, self._dropout = torch.randn, torch.randn_like, F.dropout
+
+    def _next(self):
+        v = self.items[self.pos]
+        self.pos += 1
+        return v
+
+    def __enter__(self):
+        def randn(*a, **k):
+            if self.replay:
+                return self._next().double().requires_grad_(k.get("requires_grad", False))
+            v = self._randn(*a, **k)
+            self.items.append(v.detach().clone())
+            return v
+
+        def randn_like(x, **k):
+            if self.replay:
+                return self._next().to(x.dtype)
+            v = self._randn_like(x, **k)
+            self.items.append(v.detach().clone())
+            return v
+
+        def dropout(x, p=0.5, training=True, inplace=False):
+            if not training or p == 0.0:
+                return x
+            if self.replay:
+                return x * self._next().to(x.dtype) / (1.0 - p)
+            y = self._dropout(x, p, training, False)
+            self.items.append(((y != 0) | (x == 0)).detach().clone())
+            return y
+        torch.randn, torch.randn_like, self.F.dropout = randn, randn_like, dropout
+        return self
+
+    def __exit__(self, *a):
+        torch.randn, torch.randn_like, self.F.dropout = self._randn, self._randn_like, self._dropout
+
+
+def oracle_float64_gradients(spec, aux, cfg, pre_state, post_states, tape, rows, alpha0, members):
+    """The oracle's step repeated in float64 from the same parameters, inputs and (replayed) random tensors,
+    with the fp32 run's post-phase parameters forced after every phase: per phase, the exact-arithmetic
+    gradients in the parameter order of the test."""
+    state = torch.get_rng_state()
+    tr = ref_train.OracleTrainer(spec, aux, cfg)
+    torch.set_rng_state(state)
+    mods = {"enc": tr.encoder, "dec": tr.decoder, "disc": tr.discriminator}
+    for key, m in mods.items():
+        m.load_state_dict(pre_state[key])
+        m.double().train()
+    grads = {}
+    tr.phase_hook = lambda name: grads.__setitem__(name, [
+        None if p.grad is None else p.grad.detach().clone() for grp in members[name] for p in mods[grp].parameters()])
+
+    def force(name):
+        snap = post_states[name]
+        tr.encoder.load_state_dict(snap["enc"])
+        tr.decoder.load_state_dict(snap["dec"])
+        tr.discriminator.load_state_dict(snap["dis"])
+    tr.post_hook = force
+    tape.replay, tape.pos = True, 0
+    with tape:
+        tr.train_step(torch.tensor(tr.train_spec[rows], dtype=torch.float64),
+                      torch.tensor(tr.train_aux[rows], dtype=torch.float64), alpha0, 0)
+    assert tape.pos == len(tape.items)
+    return grads
+
+
 @pytest.mark.parametrize("case,steps", [("fc_small", (1, 2, 5, 8)), ("fc_adam_nodrop", (1, 3)), ("fc_512_aux12", (2,)),
-                                        ("compact_small", (1, 2, 5, 8)), ("compact_nstyle5", (1, 3))])
+                                        ("compact_small", (1, 2, 5, 8)), ("compact_nstyle5", (1, 3)),
+                                        ("compact_b4096", (1,)), ("fc_b4096", (1,))])
 def test_p2_teacher_forced_steps(case, steps):
     g, cfg, spec, aux = load_case(case)
     torch.set_num_threads(1)
@@ -181,7 +268,15 @@ def test_p2_teacher_forced_steps(case, steps):
             rng_state = torch.get_rng_state()
         o_styles.clear()
         aux_b = torch.tensor(tr.train_aux[rows], dtype=torch.float32)
-        want = tr.train_step(torch.tensor(tr.train_spec[rows], dtype=torch.float32), aux_b, alpha0, 0)
+        arbiter = bs > 512 and k in steps       # large batches: see the gradient check below
+        if arbiter:
+            pre_state = {"enc": copy.deepcopy(tr.encoder.state_dict()), "dec": copy.deepcopy(tr.decoder.state_dict()),
+                         "disc": copy.deepcopy(tr.discriminator.state_dict())}
+            tape = RandomTape()
+            with tape:
+                want = tr.train_step(torch.tensor(tr.train_spec[rows], dtype=torch.float32), aux_b, alpha0, 0)
+        else:
+            want = tr.train_step(torch.tensor(tr.train_spec[rows], dtype=torch.float32), aux_b, alpha0, 0)
         if k not in steps:
             continue
         after = torch.get_rng_state()
@@ -190,7 +285,7 @@ def test_p2_teacher_forced_steps(case, steps):
         eng.step(len(rows), smooth=smooth)
         assert torch.equal(torch.get_rng_state(), after), "host tape consumed the generator differently"
         got = eng.losses()
-        bad = []
+        bad, report = [], []
         rank_flip = False
         for key in KEYS:
             if key == "smooth" and not smooth:
@@ -204,21 +299,38 @@ def test_p2_teacher_forced_steps(case, steps):
                         rank_flip = True
                         continue
                 bad.append(f"step {k} loss {key}: hip {got[key]!r} ref {want[key]!r}")
+        g64 = oracle_float64_gradients(spec, aux, cfg, pre_state, dict(o_post), tape, rows, alpha0, members) \
+            if arbiter else None
         for name in members:
             if name == "smoothness" and not smooth:
                 continue
             flat = hip_grads[name]
             lo = eng.opts[name].lo
             phase_max = max([float(g_.abs().max()) for g_ in o_grads[name] if g_ is not None] + [0.0])
-            for p_e, g_o in zip(e_params[name], o_grads[name]):
+            for ip, (p_e, g_o) in enumerate(zip(e_params[name], o_grads[name])):
                 off = eng.arena.off(p_e) - lo
                 mine_g = flat[off:off + p_e.numel()].view(p_e.shape).double()
                 ref_g = torch.zeros_like(mine_g) if g_o is None else g_o.double()
                 scale = float(ref_g.abs().max())
                 err = float((mine_g - ref_g).abs().max())
                 tol = 2e-2 if (rank_flip and name == "correlation") else 5e-3
+                report.append((err / (scale + 1e-30), f"{name} {names_e[id(p_e)]} err {err:.2e} |g|inf {scale:.2e} "
+                                                      f"phase max {phase_max:.2e}"))
+                if err > tol * scale + 1e-5 * phase_max + 1e-7 and g64 is not None and g64[name][ip] is not None:
+                    # Large batches: the reference's fp32 batch reductions (BatchNorm backward sums, GEMM
+                    # accumulation) are themselves ~1e-2 from exact arithmetic where gradients cancel, and the
+                    # kernels here sum in another order / in double.  The float64 repeat of the same step is the
+                    # arbiter: HIP's distance from it must be of the size of the reference's own fp32 distance (x3;
+                    # measured on fc_b4096: 1.1e-5 against 6.3e-6 on a gradient of 1.5e-3).
+                    e_hip = float((mine_g - g64[name][ip]).abs().max())
+                    e_ref = float((ref_g - g64[name][ip]).abs().max())
+                    report.append((e_hip / (scale + 1e-30), f"  ^ vs float64: hip {e_hip:.2e}, reference fp32 {e_ref:.2e}"))
+                    if e_hip <= 3.0 * e_ref + 1e-5 * phase_max + 1e-7:
+                        continue
                 if err > tol * scale + 1e-5 * phase_max + 1e-7:
                     bad.append(f"step {k} {name} grad {names_e[id(p_e)]}: err {err:.3e} vs |g|inf {scale:.3e}")
+        if os.environ.get("RAAE_P2_REPORT"):       # debugging aid: the largest relative gradient errors
+            print(f"\n{case} step {k}: " + "\n  ".join(f"{r:.2e} {what}" for r, what in sorted(report, reverse=True)[:12]))
         assert not bad, f"{case}:\n" + "\n".join(bad[:40])
         # BN running statistics follow the oracle's (momentum updates of 6 enc / 4 dec forwards)
         for mod_e, mod_o in ((eng.enc_mod, tr.encoder), (eng.dec_mod, tr.decoder)):
