@@ -20,9 +20,13 @@ P2  teacher-forced, at PHASE granularity: the oracle's state (weights, BN statis
     (rel 1e-5), and compare that phase's gradients at 2e-2.
     At BASELINE configs[2]'s batch (4096 rows; cases ``*_b4096``) the reference's fp32 batch reductions are
     themselves 0.5-1 % away from exact arithmetic on the cancelling gradients (adversarial and smoothness
-    phases), and the kernels here sum in another order: a tensor that misses 5e-3 there is judged against a
+    phases), and the kernels here sum in another order: a tensor that misses 5e-3 (in any case) is judged against a
     FLOAT64 repeat of the same oracle step (same parameters, inputs and replayed random tensors,
     ``oracle_float64_gradients``): HIP's distance from it must be within 3x the reference-fp32 distance.
+    One more legitimate discontinuity, not covered by these cases: a PReLU input that is pure rounding residue
+    (measured with another seed at B=256: T1[200, 2, 126] = +2.98e-8 here, <= 0 in the reference) picks the other
+    slope, which moves one sample's gradient at one position by ~30 % and every weight gradient upstream of it by
+    ~1/B; everything else of that step agreed with float64 to 1e-9 (RAAE_P2_REPORT / RAAE_P2_DUMP show this).
     The Adam update itself is pinned to torch.optim in tests/test_ops_gpu.py.
 Free-running K-step equality is NOT tested: the trajectory is chaotic (SURVEY finding 8).
 The engine runs in ``rng_mode="host"``: its tape is drawn from the global torch CPU
@@ -268,7 +272,7 @@ def test_p2_teacher_forced_steps(case, steps):
             rng_state = torch.get_rng_state()
         o_styles.clear()
         aux_b = torch.tensor(tr.train_aux[rows], dtype=torch.float32)
-        arbiter = bs > 512 and k in steps       # large batches: see the gradient check below
+        arbiter = k in steps       # see the gradient check below
         if arbiter:
             pre_state = {"enc": copy.deepcopy(tr.encoder.state_dict()), "dec": copy.deepcopy(tr.decoder.state_dict()),
                          "disc": copy.deepcopy(tr.discriminator.state_dict())}
@@ -299,8 +303,7 @@ def test_p2_teacher_forced_steps(case, steps):
                         rank_flip = True
                         continue
                 bad.append(f"step {k} loss {key}: hip {got[key]!r} ref {want[key]!r}")
-        g64 = oracle_float64_gradients(spec, aux, cfg, pre_state, dict(o_post), tape, rows, alpha0, members) \
-            if arbiter else None
+        g64 = None              # float64 repeat of this step, made on demand
         for name in members:
             if name == "smoothness" and not smooth:
                 continue
@@ -315,22 +318,31 @@ def test_p2_teacher_forced_steps(case, steps):
                 err = float((mine_g - ref_g).abs().max())
                 tol = 2e-2 if (rank_flip and name == "correlation") else 5e-3
                 report.append((err / (scale + 1e-30), f"{name} {names_e[id(p_e)]} err {err:.2e} |g|inf {scale:.2e} "
-                                                      f"phase max {phase_max:.2e}"))
-                if err > tol * scale + 1e-5 * phase_max + 1e-7 and g64 is not None and g64[name][ip] is not None:
-                    # Large batches: the reference's fp32 batch reductions (BatchNorm backward sums, GEMM
-                    # accumulation) are themselves ~1e-2 from exact arithmetic where gradients cancel, and the
-                    # kernels here sum in another order / in double.  The float64 repeat of the same step is the
+                                                      f"phase max {phase_max:.2e} at {int((mine_g - ref_g).abs().argmax())}"
+                                                      f"/{mine_g.numel()}"))
+                if err > tol * scale + 1e-5 * phase_max + 1e-7 and g_o is not None:
+                    if g64 is None:
+                        g64 = oracle_float64_gradients(spec, aux, cfg, pre_state, dict(o_post), tape, rows, alpha0,
+                                                       members)
+                    # The reference's fp32 batch reductions (BatchNorm backward sums, GEMM accumulation) are
+                    # themselves up to ~1e-2 from exact arithmetic where gradients cancel (more so at large
+                    # batches), and the kernels here sum in another order / in double.  The float64 repeat of the same step is the
                     # arbiter: HIP's distance from it must be of the size of the reference's own fp32 distance (x3;
                     # measured on fc_b4096: 1.1e-5 against 6.3e-6 on a gradient of 1.5e-3).
                     e_hip = float((mine_g - g64[name][ip]).abs().max())
                     e_ref = float((ref_g - g64[name][ip]).abs().max())
                     report.append((e_hip / (scale + 1e-30), f"  ^ vs float64: hip {e_hip:.2e}, reference fp32 {e_ref:.2e}"))
+                    if os.environ.get("RAAE_P2_DUMP") == f"{name}:{names_e[id(p_e)]}":
+                        torch.set_printoptions(precision=6, linewidth=200, sci_mode=True)
+                        print("hip - f64", (mine_g - g64[name][ip]).flatten()[:256])
+                        print("ref - f64", (ref_g - g64[name][ip]).flatten()[:256])
+                        print("f64", g64[name][ip].flatten()[:256])
                     if e_hip <= 3.0 * e_ref + 1e-5 * phase_max + 1e-7:
                         continue
                 if err > tol * scale + 1e-5 * phase_max + 1e-7:
                     bad.append(f"step {k} {name} grad {names_e[id(p_e)]}: err {err:.3e} vs |g|inf {scale:.3e}")
         if os.environ.get("RAAE_P2_REPORT"):       # debugging aid: the largest relative gradient errors
-            print(f"\n{case} step {k}: " + "\n  ".join(f"{r:.2e} {what}" for r, what in sorted(report, reverse=True)[:12]))
+            print(f"\n{case} step {k}: " + "\n  ".join(f"{r:.2e} {what}" for r, what in sorted(report, reverse=True)[:int(os.environ.get('RAAE_P2_REPORT'))]))
         assert not bad, f"{case}:\n" + "\n".join(bad[:40])
         # BN running statistics follow the oracle's (momentum updates of 6 enc / 4 dec forwards)
         for mod_e, mod_o in ((eng.enc_mod, tr.encoder), (eng.dec_mod, tr.decoder)):
