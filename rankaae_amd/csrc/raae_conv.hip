@@ -501,6 +501,11 @@ int pick_S(long floats_per_sample, long outputs_per_sample, int B, long lds_budg
     long S = (min_out + outputs_per_sample - 1) / outputs_per_sample;
     if (S < 1) S = 1;
     const long cap = lds_budget_floats / (floats_per_sample > 0 ? floats_per_sample : 1);
+    // large batches: about two groups per workgroup of a 512-workgroup grid, up to 4x the samples per group
+    // (fewer barriers, more loads in flight per staging pass; measured at B = 4096: 180 -> 201 steps/s, 8x: 192)
+    long want = (B + 1023) / 1024;
+    if (want > 4 * S) want = 4 * S;
+    if (S < want) S = want;
     if (S > cap) S = cap;
     if (S > B) S = B;
     if (S < 1) S = 1;
