@@ -309,6 +309,12 @@ typedef struct {
 } raae_block_wgrad_t;
 int raae_block_wgrad(const raae_block_wgrad_t* a, int* nslab, void* stream);
 
+/* raae_block_bwd_b of one residual block and raae_block_wgrad of the block AFTER it (model.py:24-174 + autograd;
+ * its data gradients are complete by then) in ONE launch: the two are independent and overlap on the chip, which
+ * at small batches is cheaper than parallel graph branches.  Same arguments and outputs as the two calls. */
+int raae_block_bwd_b_wgrad(const raae_block_bwd_b_t* b, const raae_block_wgrad_t* w, int* nparts, int* nslab,
+                           void* stream);
+
 /* Data parallel (replaces the reference's ipyparallel trial farm, sc/cmd/train_sc.py:25-45, per the
  * north star): out[i] = fixed-order sum of the slabs of element i -- the flat gradient that is then
  * averaged across ranks with one RCCL all-reduce per phase and fed to raae_adam_step as a single slab. */
@@ -338,7 +344,7 @@ int raae_event_destroy(void* ev);
 int raae_stream_sync(void* stream);
 const char* raae_error_string(int code);
 int raae_device_info(int* cu_count, int* lds_bytes, char* name, int name_len);
-#define RAAE_ABI_VERSION 4
+#define RAAE_ABI_VERSION 5
 int raae_abi_version(void);
 /* First 16 hex digits of sha256 over include/rankaae_hip.h + csrc/raae_*.{h,inc,hip} at build time
  * (build.sh); the Python loader recomputes it and refuses a library built from other sources. */

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librankaae_hip.so")
 
 RAAE_MAX_PARTS = 512
-ABI_VERSION = 4
+ABI_VERSION = 5
 IN_NONE, IN_PRELU_BN_DROP, IN_PRELU_DROP = 0, 1, 2
 OUT_RAW, OUT_STATS_PRELU, OUT_STATS_RAW, OUT_SOFTPLUS, OUT_RELU = 0, 1, 2, 3, 4
 G_DIRECT, G_SOFTPLUS, G_PRELU_BN, G_PRELU, G_RELU = 0, 1, 2, 3, 4
@@ -140,6 +140,7 @@ SIGNATURES = {
     "raae_block_bwd_b": (_I, [C.POINTER(BlockBwdBT), _PI, _P]),
     "raae_block_bwd_a": (_I, [C.POINTER(BlockBwdAT), _PI, _P]),
     "raae_block_wgrad": (_I, [C.POINTER(BlockWgradT), _PI, _P]),
+    "raae_block_bwd_b_wgrad": (_I, [C.POINTER(BlockBwdBT), C.POINTER(BlockWgradT), _PI, _PI, _P]),
     "raae_slab_reduce": (_I, [_P, _L, _P, _L, _P, _I, _P]),
     "raae_step_tick": (_I, [_P, _I, C.c_uint, _P, _P, _I, _P]),
     "raae_rng_fill": (_I, [_P, _P, _P, _I, _L, C.c_ulonglong, _P, _P]),

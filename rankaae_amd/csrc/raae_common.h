@@ -175,6 +175,16 @@ __device__ __forceinline__ int group_multi_slot(int lane) {       // bit k of th
 // into LDS with ONE coalesced vector load per thread.  Scalar s_loads of a 600-byte struct come out as a
 // chain of dependent cache-line misses (the kernarg buffer is fresh for every launch): several
 // microseconds at the head of a kernel that runs for ten.  All threads call it; ends with a barrier.
+// The same for an argument block that starts `byte_off` bytes (a multiple of 4) into the kernarg segment.
+template <typename T>
+__device__ __forceinline__ const T& args_to_lds_at(T* slot, int byte_off) {
+    typedef __attribute__((address_space(4))) const unsigned* kptr_t;
+    const kptr_t kp = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr() + byte_off / 4;
+    unsigned* dst = reinterpret_cast<unsigned*>(slot);
+    for (int i = threadIdx.x; i < (int)(sizeof(T) / 4); i += blockDim.x) dst[i] = kp[i];
+    __syncthreads();
+    return *slot;
+}
 template <typename T>
 __device__ __forceinline__ const T& args_to_lds(T* slot) {
     typedef __attribute__((address_space(4))) const unsigned* kptr_t;

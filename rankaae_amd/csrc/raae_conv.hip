@@ -15,6 +15,7 @@ __device__ long long d_stage_prev[4];
 #include "raae_common.h"
 #include <string.h>
 #include <stdlib.h>
+#include <stddef.h>
 
 namespace {
 
@@ -783,7 +784,8 @@ extern "C" int raae_block_fwd_b(const raae_block_fwd_b_t* in, int* nparts, void*
     RAAE_LAUNCH_RET();
 }
 
-extern "C" int raae_block_bwd_b(const raae_block_bwd_b_t* in, int* nparts, void* stream) {
+// checks + launch geometry of backward phase B (shared by raae_block_bwd_b and raae_block_bwd_b_wgrad)
+static int prep_block_bwd_b(const raae_block_bwd_b_t* in, raae_block_bwd_b_t& a, int& grid, size_t& lds, int& kind) {
     RAAE_CHECK_ARG(in && in->B > 0 && in->Cin >= 1 && in->Cin <= CT_MAXCH && in->Cout >= 1 && in->Cout <= CT_MAXCH);
     RAAE_CHECK_ARG(in->gy.g && (!in->gy.has_bn || (in->gy.u && in->gy.g_partials && in->gy.bn.partials &&
                                                   in->gy.g_nparts > 0 && in->gy.g_nparts <= RAAE_MAX_PARTS)));
@@ -792,7 +794,7 @@ extern "C" int raae_block_bwd_b(const raae_block_bwd_b_t* in, int* nparts, void*
     RAAE_CHECK_ARG(in->has_excit || in->Cin == in->Cout);
     RAAE_CHECK_ARG(in->T2 && in->Ex && in->dT2 && in->dSh && in->dEx && in->dBn2 && in->pdBn2 && in->dslope2 && in->dslope_e);
     RAAE_CHECK_ARG(!in->has_short || (in->Sh && in->ss && in->dslope_s));
-    raae_block_bwd_b_t a = *in;
+    a = *in;
     const long per = (long)a.Cout * a.Lout * (a.has_excit ? 2 : 1);
     RAAE_CHECK_ARG(per <= kTileBudget);
     long widest = (long)a.Cout * a.Lout;
@@ -800,10 +802,19 @@ extern "C" int raae_block_bwd_b(const raae_block_bwd_b_t* in, int* nparts, void*
     a.S = pick_S(per, widest, a.B, kTileBudget, 256);
     a.ngroups = (a.B + a.S - 1) / a.S;
     a.sh_l1 = lg2(a.L1); a.sh_lout = lg2(a.Lout);
-    const int grid = a.ngroups < 512 ? a.ngroups : 512;
+    grid = a.ngroups < 512 ? a.ngroups : 512;
+    lds = sizeof(float) * ((size_t)a.S * per + conv_nw(&a.cv2) + (a.has_excit ? conv_nw(&a.cve) : 0));
+    kind = blk_kind_b(a.Cin, a.Cout, a.L1, a.Lout, a.cv2, a.has_short, a.has_excit, a.cve);
+    return 0;
+}
+
+extern "C" int raae_block_bwd_b(const raae_block_bwd_b_t* in, int* nparts, void* stream) {
+    raae_block_bwd_b_t a;
+    int grid, kind;
+    size_t lds;
+    const int rc = prep_block_bwd_b(in, a, grid, lds, kind);
+    if (rc) return rc;
     if (nparts) *nparts = grid;
-    const size_t lds = sizeof(float) * ((size_t)a.S * per + conv_nw(&a.cv2) + (a.has_excit ? conv_nw(&a.cve) : 0));
-    const int kind = blk_kind_b(a.Cin, a.Cout, a.L1, a.Lout, a.cv2, a.has_short, a.has_excit, a.cve);
     RAAE_LAUNCH_KIND(block_bwd_b_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a)
     RAAE_LAUNCH_RET();
 }
@@ -837,10 +848,11 @@ extern "C" int raae_block_bwd_a(const raae_block_bwd_a_t* in, int* nparts, void*
 
 // workgroups per weight-gradient task (= slabs it writes); 64 -> 128: +2 % at B=256, +18 % at B=4096
 static const int kWgradTaskGrid = 128;
-extern "C" int raae_block_wgrad(const raae_block_wgrad_t* in, int* nslab, void* stream) {
+// checks + task table + launch geometry of a block's weight-gradient tasks; `m` is filled
+static int prep_block_wgrad(const raae_block_wgrad_t* in, int* nslab, WgradMultiArgs& m, int& total_out, size_t& dyn_out,
+                            int& kind_out) {
     RAAE_CHECK_ARG(in && nslab && in->B > 0 && in->n_conv >= 0 && in->n_conv <= 4 && in->n_lin >= 0 && in->n_lin <= 2 &&
                    in->n_conv + in->n_lin > 0);
-    static thread_local WgradMultiArgs m;   // large (kernarg by value); per-thread host scratch, filled per call
     m.ntask = 0;
     int total = 0;
     size_t dyn = 0;
@@ -899,6 +911,59 @@ extern "C" int raae_block_wgrad(const raae_block_wgrad_t* in, int* nslab, void* 
         if (all) kind = k;
     }
     if (kind < 0) for (int i = 0; i < 4; ++i) m.which[i] = 0;
+    total_out = total; dyn_out = dyn; kind_out = kind;
+    return 0;
+}
+
+extern "C" int raae_block_wgrad(const raae_block_wgrad_t* in, int* nslab, void* stream) {
+    static thread_local WgradMultiArgs m;   // large (kernarg by value); per-thread host scratch, filled per call
+    int total, kind;
+    size_t dyn;
+    const int rc = prep_block_wgrad(in, nslab, m, total, dyn, kind);
+    if (rc) return rc;
     RAAE_LAUNCH_KIND(wgrad_multi_kernel, dim3(total), dim3(256), dyn, (hipStream_t)stream, m)
+    RAAE_LAUNCH_RET();
+}
+
+// Backward phase B of one residual block and ALL weight-gradient tasks of the block after it (whose data
+// gradients are complete) in ONE launch: workgroups [0, nb) run block_bwd_b, the rest the weight-gradient tasks.
+// The two are independent, so they overlap on the chip like parallel graph branches would -- without the
+// fork/join edges, which at 256-row batches cost as much as the kernels.
+struct BwdBWgradArgs { BlockBwdBArgs b; WgradMultiArgs w; int nb; };
+template <int KB, int KW>
+__global__ __launch_bounds__(256) void block_bwd_b_wgrad_kernel(BwdBWgradArgs k) {
+    extern __shared__ __attribute__((aligned(16))) float dyn[];
+    const int nb = k.nb;
+    if ((int)blockIdx.x < nb) {
+        __shared__ BlockBwdBArgs sa;
+        const BlockBwdBArgs& a = raae::args_to_lds_at(&sa, (int)offsetof(BwdBWgradArgs, b));
+        block_bwd_b_body<KB>(a, blockIdx.x, nb, dyn);
+    } else {
+        __shared__ WgradMultiArgs sm;
+        const WgradMultiArgs& m = raae::args_to_lds_at(&sm, (int)offsetof(BwdBWgradArgs, w));
+        wgrad_multi_body<KW>(m, blockIdx.x - nb, dyn);
+    }
+}
+
+extern "C" int raae_block_bwd_b_wgrad(const raae_block_bwd_b_t* bin, const raae_block_wgrad_t* win, int* nparts,
+                                      int* nslab, void* stream) {
+    static thread_local BwdBWgradArgs k;
+    int gridb, kindb, total, kindw;
+    size_t ldsb, dynw;
+    int rc = prep_block_bwd_b(bin, k.b, gridb, ldsb, kindb);
+    if (rc) return rc;
+    rc = prep_block_wgrad(win, nslab, k.w, total, dynw, kindw);
+    if (rc) return rc;
+    if (nparts) *nparts = gridb;
+    k.nb = gridb;
+    const size_t lds = ldsb > dynw ? ldsb : dynw;
+    const dim3 grid(gridb + total), block(256);
+    // instances: phase B of block i-1 beside the weight gradients of block i, for the block sequences of the
+    // 256-point networks (encoder 0,1,2; decoder 3,4,5,6); anything else runs the generic pair
+#define RAAE_PAIR(KB_, KW_) if (kindb == KB_ && kindw == KW_) { \
+        hipLaunchKernelGGL((block_bwd_b_wgrad_kernel<KB_, KW_>), grid, block, lds, (hipStream_t)stream, k); RAAE_LAUNCH_RET(); }
+    RAAE_PAIR(0, 1) RAAE_PAIR(1, 2) RAAE_PAIR(3, 4) RAAE_PAIR(4, 5) RAAE_PAIR(5, 6)
+#undef RAAE_PAIR
+    hipLaunchKernelGGL((block_bwd_b_wgrad_kernel<-1, -1>), grid, block, lds, (hipStream_t)stream, k);
     RAAE_LAUNCH_RET();
 }

@@ -252,6 +252,22 @@ class CompactNet:
             ws.ndBnF = ops.conv_bwd_data(go, b, self.cvf, self.conv_f.weight, vf, ws.dBnF, False, ws.pdBnF)
             gy = dict(g=ws.dBnF, bn=self.bn_f, parts=ws.pdBnF, nparts=ws.ndBnF)
 
+        # Serial chain (batches below eng.overlap_min_batch): a block's weight-gradient tasks wait as `pending` and
+        # ride in the launch of the NEXT block's backward phase B (raae_block_bwd_b_wgrad); the last ones go alone.
+        pending = None
+
+        def note_wgrad(pend, ns):
+            _, convs_, lins_ = pend
+            for (_, _, _, mod), n_ in zip(convs_, ns):
+                eng.note_slabs([mod.weight, mod.bias], n_)
+            for (_, _, _, _, _, mod), n_ in zip(lins_, ns[len(convs_):]):
+                eng.note_slabs([mod.weight, mod.bias], n_)
+
+        def flush(pend):
+            if pend is not None:
+                note_wgrad(pend, ops.block_wgrad(b, None, None, eng.arena.n, args=pend[0]))
+            return None
+
         for i in reversed(range(len(self.blocks))):
             k, w, m = self.blocks[i], ws.blk[i], self.blocks[i].m
             need_dx = i > 0 or dx_in is not None
@@ -270,8 +286,14 @@ class CompactNet:
                 v1 = ops.make_view(w.T1, m.relu1.weight, bn2v)
                 bne = self._bn(m.bn_excit, w.pE2, w.nE2, b * k.Lout, True, False) if k.cve is not None else None
                 ve2 = ops.make_view(w.E2, m.relu_excit_2.weight, bne)
-                nB = ops.block_bwd_b(gspec(None, None), v1, ve2 if k.cve is not None else None, b, k, m, w,
-                                     eng.arena.n, G)
+                if pending is not None:
+                    nB, ns_w = ops.block_bwd_b(gspec(None, None), v1, ve2 if k.cve is not None else None, b, k, m, w,
+                                               eng.arena.n, G, wgrad=pending[0])
+                    note_wgrad(pending, ns_w)
+                    pending = None
+                else:
+                    nB = ops.block_bwd_b(gspec(None, None), v1, ve2 if k.cve is not None else None, b, k, m, w,
+                                         eng.arena.n, G)
                 eng.note_slabs([m.relu2.weight] + ([m.relu_short.weight] if k.cvs is not None else []) +
                                [m.relu_excit_3.weight if k.cve is not None else m.relu_excit_2.weight], nB)
                 g1 = ops.make_grad(w.dBn2, raw=w.T1, slope=m.relu1.weight, bn=bn2v, g_partials=w.pdBn2, g_nparts=nB)
@@ -288,7 +310,6 @@ class CompactNet:
                 # joined first.  (Measured on ROCm 7.2: with deeper cross-block overlap a captured graph
                 # stopped being bitwise equal to eager launches although its dependency edges were
                 # complete -- tests/test_engine_gpu.py::test_graph_replay_is_bitwise_eager guards this.)
-                eng.join_side_streams()
                 G_ = eng.gslab
                 convs = [(ops.make_grad(w.dT2), k.cv2, v1, m.conv2), (ops.make_grad(w.dT1), k.cv1, vR(), m.conv1)]
                 if k.cve is not None:
@@ -302,21 +323,25 @@ class CompactNet:
                 nbytes = sum(4 * b * (cv_.Cin * cv_.Lin + cv_.Cout * cv_.Lout) + 4 * (mod.weight.numel() + cv_.Cout)
                              for _, cv_, _, mod in convs)
                 nbytes += sum(4 * b * c_ * (e_ + l_) + 4 * (e_ * l_ + e_) for _, c_, e_, l_, _, _ in lins)
-                with eng.side_stream():
-                    ns = eng.probe_launch("block_wgrad", nbytes, lambda: ops.block_wgrad(
-                        b, [(g_, cv_, v_, G_(mod.weight), G_(mod.bias)) for g_, cv_, v_, mod in convs],
-                        [(g_, c_, e_, l_, v_, G_(mod.weight), G_(mod.bias)) for g_, c_, e_, l_, v_, mod in lins],
-                        eng.arena.n))
-                for (_, _, _, mod), n_ in zip(convs, ns):
-                    eng.note_slabs([mod.weight, mod.bias], n_)
-                for (_, _, _, _, _, mod), n_ in zip(lins, ns[len(convs):]):
-                    eng.note_slabs([mod.weight, mod.bias], n_)
+                wargs = ops.block_wgrad_args(
+                    b, [(g_, cv_, v_, G_(mod.weight), G_(mod.bias)) for g_, cv_, v_, mod in convs],
+                    [(g_, c_, e_, l_, v_, G_(mod.weight), G_(mod.bias)) for g_, c_, e_, l_, v_, mod in lins],
+                    eng.arena.n)
+                if eng._branch:
+                    eng.join_side_streams()
+                    with eng.side_stream():
+                        ns = eng.probe_launch("block_wgrad", nbytes,
+                                              lambda: ops.block_wgrad(b, None, None, eng.arena.n, args=wargs))
+                    note_wgrad((wargs, convs, lins), ns)
+                else:
+                    pending = (wargs, convs, lins)
                 if i > 0:
                     gy = dict(g=w.dR, bn=m.bn1, parts=w.pdR, nparts=w.ndR)
                     if m.bn1 is None:
                         gy = dict(g=w.dR, bn=None, parts=None, nparts=0)
                 continue
             # ---- main branch
+            pending = flush(pending)
             go2 = gspec(w.T2, m.relu2.weight)
             v1 = ops.make_view(w.T1, m.relu1.weight, self._bn(m.bn2, w.pT1, w.nT1, b * k.L1, True, False))
             self._cw(go2, b, k.cv2, v1, m.conv2, m.relu2)
@@ -359,3 +384,4 @@ class CompactNet:
                 gy = dict(g=w.dR, bn=m.bn1, parts=w.pdR, nparts=w.ndR)
                 if m.bn1 is None:
                     gy = dict(g=w.dR, bn=None, parts=None, nparts=0)
+        flush(pending)

@@ -342,7 +342,7 @@ def block_fwd_b(vT1, vE2, vR, B, k, m, Sh, T2, E3, Y, pY):
     return n.value
 
 
-def block_bwd_b(gy, vT1, vE2, B, k, m, w, slab_stride, gslab):
+def block_bwd_b(gy, vT1, vE2, B, k, m, w, slab_stride, gslab, wgrad=None):
     """Fused backward phase B (``w``: the block's workspace, ``gslab(p)``: slab-0 view of parameter p)."""
     a = _lib.BlockBwdBT()
     a.gy, a.vT1 = gy, vT1
@@ -366,6 +366,11 @@ def block_bwd_b(gy, vT1, vE2, B, k, m, w, slab_stride, gslab):
     a.dT2, a.dSh, a.dEx, a.dBn2, a.pdBn2 = _p(w.dT2), _p(w.dSh), _p(w.dEx), _p(w.dBn2), _p(w.pdBn2)
     a.dslope2 = _p(gslab(m.relu2.weight))
     a.slab_stride = slab_stride
+    if wgrad is not None:          # the following block's weight-gradient tasks ride in the same launch
+        n, ns = C.c_int(0), (C.c_int * 6)()
+        check(_lib.load().raae_block_bwd_b_wgrad(C.byref(a), C.byref(wgrad), C.byref(n), ns, _stream()),
+              "raae_block_bwd_b_wgrad")
+        return n.value, list(ns)[:wgrad.n_conv + wgrad.n_lin]
     n = C.c_int(0)
     check(_lib.load().raae_block_bwd_b(C.byref(a), C.byref(n), _stream()), "raae_block_bwd_b")
     return n.value
@@ -396,9 +401,8 @@ def block_bwd_a(g1, ge, view_in, mask, B, k, m, w, dE2, dR, pdR, slab_stride, gs
     return n.value
 
 
-def block_wgrad(B, conv_tasks, lin_tasks, slab_stride):
-    """``conv_tasks``: [(grad, conv_desc, view, dw, dbias)], ``lin_tasks``: [(grad, C, E, Lin, view, dw, dbias)].
-    One launch; returns the slab count per task (conv tasks first)."""
+def block_wgrad_args(B, conv_tasks, lin_tasks, slab_stride):
+    """The ``raae_block_wgrad_t`` of ``block_wgrad`` (to be launched later, e.g. inside ``block_bwd_b(wgrad=...)``)."""
     a = _lib.BlockWgradT()
     a.n_conv, a.n_lin, a.B, a.slab_stride = len(conv_tasks), len(lin_tasks), B, slab_stride
     for i, (go, cv, view, dw, db) in enumerate(conv_tasks):
@@ -407,6 +411,13 @@ def block_wgrad(B, conv_tasks, lin_tasks, slab_stride):
     for i, (go, Cc, E, Lin, view, dw, db) in enumerate(lin_tasks):
         a.lin[i].go, a.lin[i].C, a.lin[i].E, a.lin[i].Lin, a.lin[i].inp = go, Cc, E, Lin, view
         a.lin[i].dw, a.lin[i].dbias = dw.data_ptr(), db.data_ptr()
+    return a
+
+
+def block_wgrad(B, conv_tasks, lin_tasks, slab_stride, args=None):
+    """``conv_tasks``: [(grad, conv_desc, view, dw, dbias)], ``lin_tasks``: [(grad, C, E, Lin, view, dw, dbias)].
+    One launch; returns the slab count per task (conv tasks first)."""
+    a = args if args is not None else block_wgrad_args(B, conv_tasks, lin_tasks, slab_stride)
     ns = (C.c_int * 6)()
     check(_lib.load().raae_block_wgrad(C.byref(a), ns, _stream()), "raae_block_wgrad")
-    return list(ns)[:len(conv_tasks) + len(lin_tasks)]
+    return list(ns)[:a.n_conv + a.n_lin]
