@@ -228,9 +228,10 @@ class FCNet:
             eng.count_bn(self.bn_modules)
         return ws.out
 
-    def backward(self, ws, x, masks, g_out, dx_in=None):
+    def backward(self, ws, x, masks, g_out, dx_in=None, pending=None, keep_pending=False):
         """``g_out``: dL/d(output).  Writes parameter-gradient slabs; returns dL/d(input) in
         ``dx_in`` (if given).  Records the slab count of every parameter it touched."""
+        assert pending is None     # (the conv networks hand weight-gradient tasks across; the dense ones have none)
         eng, L, b = self.eng, self.layers, ws.b
         n = len(L)
         if self.kind == "enc":
@@ -703,8 +704,8 @@ class StepEngine:
         out = dec.forward(D, styles, P.m_dec[1])
         n = ops.recon_loss_fwd_bwd(P.spec, out, b, self.L, c["use_flex_spec_target"], P.lpart, P.dout)
         ops.loss_finalize(P.lpart, n, 1.0, lo, 2)
-        dec.backward(D, styles, P.m_dec[1], P.dout, P.dstyles)
-        enc.backward(E, P.spec, P.m_enc[2], P.dstyles)
+        left = dec.backward(D, styles, P.m_dec[1], P.dout, P.dstyles, keep_pending=True)
+        enc.backward(E, P.spec, P.m_enc[2], P.dstyles, pending=left)
         self._adam(P, "reconstruction", self._slab_notes)
         # ---- phase D: mutual information (:175-186)
         self._begin_phase(record)
@@ -716,8 +717,8 @@ class StepEngine:
         z_rec = enc.forward(E, out, P.m_enc[4])
         n = ops.mse_fwd_bwd(z_rec, z_s, b * ns, P.lpart, P.dstyles)
         ops.loss_finalize(P.lpart, n, 1.0, lo, 3, 5)
-        enc.backward(E, out, P.m_enc[4], P.dstyles, P.dspec)
-        dec.backward(D, z_s, P.m_dec[2], P.dspec, None)
+        left = enc.backward(E, out, P.m_enc[4], P.dstyles, P.dspec, keep_pending=True)
+        dec.backward(D, z_s, P.m_dec[2], P.dspec, None, pending=left)
         self._adam(P, "mutual_info", self._slab_notes)
         # ---- phase E: smoothness (:189-200); encoder gradients are discarded by the reference
         if smooth:

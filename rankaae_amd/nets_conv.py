@@ -232,7 +232,9 @@ class CompactNet:
         return ws.out
 
     # ------------------------------------------------------------------ backward
-    def backward(self, ws, x, masks, g_out, dx_in=None):
+    def backward(self, ws, x, masks, g_out, dx_in=None, pending=None, keep_pending=False):
+        """``pending``: weight-gradient tasks another network's backward left over (its return value with
+        ``keep_pending``): they ride in this network's first fused launch instead of a launch of their own."""
         eng, b = self.eng, ws.b
         G = eng.gslab
         last, wl = self.blocks[-1], ws.blk[-1]
@@ -253,8 +255,8 @@ class CompactNet:
             gy = dict(g=ws.dBnF, bn=self.bn_f, parts=ws.pdBnF, nparts=ws.ndBnF)
 
         # Serial chain (batches below eng.overlap_min_batch): a block's weight-gradient tasks wait as `pending` and
-        # ride in the launch of the NEXT block's backward phase B (raae_block_bwd_b_wgrad); the last ones go alone.
-        pending = None
+        # ride in the launch of the NEXT block's backward phase B (raae_block_bwd_b_wgrad); the last ones go alone
+        # or are handed to the network whose backward follows.
 
         def note_wgrad(pend, ns):
             _, convs_, lins_ = pend
@@ -384,4 +386,7 @@ class CompactNet:
                 gy = dict(g=w.dR, bn=m.bn1, parts=w.pdR, nparts=w.ndR)
                 if m.bn1 is None:
                     gy = dict(g=w.dR, bn=None, parts=None, nparts=0)
+        if keep_pending:
+            return pending
         flush(pending)
+        return None
