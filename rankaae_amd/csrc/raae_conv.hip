@@ -964,6 +964,7 @@ extern "C" int raae_block_bwd_b_wgrad(const raae_block_bwd_b_t* bin, const raae_
         hipLaunchKernelGGL((block_bwd_b_wgrad_kernel<KB_, KW_>), grid, block, lds, (hipStream_t)stream, k); RAAE_LAUNCH_RET(); }
     RAAE_PAIR(0, 1) RAAE_PAIR(1, 2) RAAE_PAIR(3, 4) RAAE_PAIR(4, 5) RAAE_PAIR(5, 6)
     RAAE_PAIR(2, 3) RAAE_PAIR(6, 0)      // across the networks: encoder's last block beside decoder block 0's tasks, and back
+    RAAE_PAIR(6, -1)                     // the decoder's head conv (a lone generic task) beside its last block
 #undef RAAE_PAIR
     hipLaunchKernelGGL((block_bwd_b_wgrad_kernel<-1, -1>), grid, block, lds, (hipStream_t)stream, k);
     RAAE_LAUNCH_RET();

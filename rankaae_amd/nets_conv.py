@@ -250,7 +250,13 @@ class CompactNet:
         else:
             go = ops.make_grad(g_out.view(b, 1, self.out_dim), raw=ws.spec.view(b, 1, self.out_dim), act=self.act)
             vf = ops.make_view(wl.Y, None, self._bn(self.bn_f, wl.pY, wl.nY, b * last.Lout, True, False))
-            self._cw(go, b, self.cvf, vf, self.conv_f, None)
+            if pending is None and not eng._branch and self.fused and last.Cin <= 8 and last.Cout <= 8:
+                # serial chain: the head's weight gradient rides in the last block's backward phase B
+                head = [(go, self.cvf, vf, self.conv_f)]
+                pending = (ops.block_wgrad_args(b, [(go, self.cvf, vf, G(self.conv_f.weight), G(self.conv_f.bias))], [],
+                                                eng.arena.n), head, [])
+            else:
+                self._cw(go, b, self.cvf, vf, self.conv_f, None)
             ws.ndBnF = ops.conv_bwd_data(go, b, self.cvf, self.conv_f.weight, vf, ws.dBnF, False, ws.pdBnF)
             gy = dict(g=ws.dBnF, bn=self.bn_f, parts=ws.pdBnF, nparts=ws.ndBnF)
 
