@@ -259,6 +259,15 @@ typedef struct {
 int raae_block_fwd_a(const raae_block_fwd_a_t* a, int* nparts, void* stream);
 int raae_block_fwd_b(const raae_block_fwd_b_t* a, int* nparts, void* stream);
 
+/* raae_block_fwd_a / raae_block_fwd_b of TWO residual blocks that do not depend on each other, in ONE launch: of the
+ * six encoder and four decoder forwards of a step (trainer.py:113-200) two are run only for their BatchNorm /
+ * RNG side effects, and each of those chains runs beside a chain that is needed.  Same arguments and outputs
+ * as the two single calls. */
+int raae_block_fwd_a2(const raae_block_fwd_a_t* x, const raae_block_fwd_a_t* y, int* nparts_x, int* nparts_y,
+                      void* stream);
+int raae_block_fwd_b2(const raae_block_fwd_b_t* x, const raae_block_fwd_b_t* y, int* nparts_x, int* nparts_y,
+                      void* stream);
+
 /* ---- fused residual-block backward, data gradients (mirror of the forward split) ----
  *   B: dY = BNbwd(gy) -> dT2, dSh (= dY when the shortcut is the identity), dEx (= dE3, or dE2 when the block has no
  *      conv_excit) materialised once; dBn2 = conv2^T dT2 and dBnE = conv_excit^T dE3 with their BatchNorm-backward
@@ -344,7 +353,7 @@ int raae_event_destroy(void* ev);
 int raae_stream_sync(void* stream);
 const char* raae_error_string(int code);
 int raae_device_info(int* cu_count, int* lds_bytes, char* name, int name_len);
-#define RAAE_ABI_VERSION 5
+#define RAAE_ABI_VERSION 6
 int raae_abi_version(void);
 /* First 16 hex digits of sha256 over include/rankaae_hip.h + csrc/raae_*.{h,inc,hip} at build time
  * (build.sh); the Python loader recomputes it and refuses a library built from other sources. */

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librankaae_hip.so")
 
 RAAE_MAX_PARTS = 512
-ABI_VERSION = 5
+ABI_VERSION = 6
 IN_NONE, IN_PRELU_BN_DROP, IN_PRELU_DROP = 0, 1, 2
 OUT_RAW, OUT_STATS_PRELU, OUT_STATS_RAW, OUT_SOFTPLUS, OUT_RELU = 0, 1, 2, 3, 4
 G_DIRECT, G_SOFTPLUS, G_PRELU_BN, G_PRELU, G_RELU = 0, 1, 2, 3, 4
@@ -137,6 +137,8 @@ SIGNATURES = {
     "raae_grad_materialize": (_I, [_PG, _I, _I, _I, _P, _I, _P, _L, _PI, _P]),
     "raae_block_fwd_a": (_I, [C.POINTER(BlockFwdAT), _PI, _P]),
     "raae_block_fwd_b": (_I, [C.POINTER(BlockFwdBT), _PI, _P]),
+    "raae_block_fwd_a2": (_I, [C.POINTER(BlockFwdAT), C.POINTER(BlockFwdAT), _PI, _PI, _P]),
+    "raae_block_fwd_b2": (_I, [C.POINTER(BlockFwdBT), C.POINTER(BlockFwdBT), _PI, _PI, _P]),
     "raae_block_bwd_b": (_I, [C.POINTER(BlockBwdBT), _PI, _P]),
     "raae_block_bwd_a": (_I, [C.POINTER(BlockBwdAT), _PI, _P]),
     "raae_block_wgrad": (_I, [C.POINTER(BlockWgradT), _PI, _P]),

@@ -736,13 +736,13 @@ static int blk_kind_b(int Cin, int Cout, int L1, int Lout, const raae_conv_t& cv
     return -1;
 }
 
-extern "C" int raae_block_fwd_a(const raae_block_fwd_a_t* in, int* nparts, void* stream) {
+static int prep_block_fwd_a(const raae_block_fwd_a_t* in, raae_block_fwd_a_t& a, int& grid, size_t& lds, int& kind) {
     RAAE_CHECK_ARG(in && in->B > 0 && in->Cin >= 1 && in->Cin <= CT_MAXCH && in->Cout >= 1 && in->Cout <= CT_MAXCH);
     RAAE_CHECK_ARG(view_ok(&in->in, in->Cin) && !in->in.mask && conv_ok(&in->cv1) && (!in->has_short || conv_ok(&in->cvs)));
     RAAE_CHECK_ARG(in->T1 && in->E1 && in->E2 && in->pT1 && (!in->has_short || in->Sh));
     RAAE_CHECK_ARG(in->cv1.Cin == in->Cin && in->cv1.Cout == in->Cout && in->cv1.Lin == in->Lin && in->cv1.Lout == in->L1);
     RAAE_CHECK_ARG(!in->has_short || (in->cvs.Lin == in->Lin && in->cvs.Lout == in->Lout && in->cvs.pad == 0));
-    raae_block_fwd_a_t a = *in;
+    a = *in;
     a.halo = a.cv1.transposed ? 0 : a.cv1.pad;
     const long wfl = conv_nw(&a.cv1) + (a.has_short ? conv_nw(&a.cvs) : 0) + 2L * a.E * (a.Lin > a.Lout ? a.Lin : a.Lout);
     const long per = (long)a.Cin * (a.Lin + 2 * a.halo) + (long)a.Cin * a.E;
@@ -753,22 +753,31 @@ extern "C" int raae_block_fwd_a(const raae_block_fwd_a_t* in, int* nparts, void*
     a.S = pick_S(per, outs, a.B, kTileBudget, 256);
     a.ngroups = (a.B + a.S - 1) / a.S;
     a.sh_lin = lg2(a.Lin); a.sh_l1 = lg2(a.L1); a.sh_lout = lg2(a.Lout); a.sh_e = lg2(a.E);
-    const int grid = a.ngroups < RAAE_MAX_PARTS ? a.ngroups : RAAE_MAX_PARTS;
-    if (nparts) *nparts = grid;
-    const size_t lds = sizeof(float) * ((size_t)a.S * per + conv_nw(&a.cv1) + (a.has_short ? conv_nw(&a.cvs) : 0) +
+    grid = a.ngroups < RAAE_MAX_PARTS ? a.ngroups : RAAE_MAX_PARTS;
+    lds = sizeof(float) * ((size_t)a.S * per + conv_nw(&a.cv1) + (a.has_short ? conv_nw(&a.cvs) : 0) +
                                         (size_t)a.E * a.Lin + (size_t)a.Lout * a.E);
-    const int kind = blk_kind_a(a.Cin, a.Cout, a.Lin, a.L1, a.Lout, a.E, a.cv1, a.has_short, a.cvs, 0, false);
+    kind = blk_kind_a(a.Cin, a.Cout, a.Lin, a.L1, a.Lout, a.E, a.cv1, a.has_short, a.cvs, 0, false);
+    return 0;
+}
+
+extern "C" int raae_block_fwd_a(const raae_block_fwd_a_t* in, int* nparts, void* stream) {
+    raae_block_fwd_a_t a;
+    int grid, kind;
+    size_t lds;
+    const int rc = prep_block_fwd_a(in, a, grid, lds, kind);
+    if (rc) return rc;
+    if (nparts) *nparts = grid;
     RAAE_LAUNCH_KIND(block_fwd_a_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a)
     RAAE_LAUNCH_RET();
 }
 
-extern "C" int raae_block_fwd_b(const raae_block_fwd_b_t* in, int* nparts, void* stream) {
+static int prep_block_fwd_b(const raae_block_fwd_b_t* in, raae_block_fwd_b_t& a, int& grid, size_t& lds, int& kind) {
     RAAE_CHECK_ARG(in && in->B > 0 && in->Cin >= 1 && in->Cin <= CT_MAXCH && in->Cout >= 1 && in->Cout <= CT_MAXCH);
     RAAE_CHECK_ARG(view_ok(&in->vT1, in->Cout) && view_ok(&in->vE2, in->Cin) && conv_ok(&in->cv2));
     RAAE_CHECK_ARG(in->has_short ? (in->Sh && in->ss) : (view_ok(&in->vR, in->Cin) && in->Cin == in->Cout));
     RAAE_CHECK_ARG(in->has_excit ? (conv_ok(&in->cve) && in->E3 && in->cve.K == 1) : in->Cin == in->Cout);
     RAAE_CHECK_ARG(in->T2 && in->Y && in->pY && in->cv2.Lin == in->L1 && in->cv2.Lout == in->Lout);
-    raae_block_fwd_b_t a = *in;
+    a = *in;
     a.halo2 = a.cv2.transposed ? 0 : a.cv2.pad;
     RAAE_CHECK_ARG(a.cv2.transposed || !a.cv2.pad_replicate);
     const long per = (long)a.Cout * (a.L1 + 2 * a.halo2) + (a.has_excit ? (long)a.Cin * a.Lout : 0);
@@ -776,13 +785,105 @@ extern "C" int raae_block_fwd_b(const raae_block_fwd_b_t* in, int* nparts, void*
     a.S = pick_S(per, (long)a.Cout * a.Lout, a.B, kTileBudget, 256);
     a.ngroups = (a.B + a.S - 1) / a.S;
     a.sh_l1 = lg2(a.L1); a.sh_lout = lg2(a.Lout);
-    const int grid = a.ngroups < RAAE_MAX_PARTS ? a.ngroups : RAAE_MAX_PARTS;
+    grid = a.ngroups < RAAE_MAX_PARTS ? a.ngroups : RAAE_MAX_PARTS;
+    lds = sizeof(float) * ((size_t)a.S * per + conv_nw(&a.cv2) + (a.has_excit ? conv_nw(&a.cve) : 0));
+    kind = blk_kind_b(a.Cin, a.Cout, a.L1, a.Lout, a.cv2, a.has_short, a.has_excit, a.cve);
+    return 0;
+}
+
+extern "C" int raae_block_fwd_b(const raae_block_fwd_b_t* in, int* nparts, void* stream) {
+    raae_block_fwd_b_t a;
+    int grid, kind;
+    size_t lds;
+    const int rc = prep_block_fwd_b(in, a, grid, lds, kind);
+    if (rc) return rc;
     if (nparts) *nparts = grid;
-    const size_t lds = sizeof(float) * ((size_t)a.S * per + conv_nw(&a.cv2) + (a.has_excit ? conv_nw(&a.cve) : 0));
-    const int kind = blk_kind_b(a.Cin, a.Cout, a.L1, a.Lout, a.cv2, a.has_short, a.has_excit, a.cve);
     RAAE_LAUNCH_KIND(block_fwd_b_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a)
     RAAE_LAUNCH_RET();
 }
+
+// The same forward phase of TWO residual blocks that do not depend on each other (one of the encoder, one of the
+// decoder: the forward chain whose result the reference throws away runs beside a forward chain that is needed)
+// in ONE launch: workgroups [0, n1) run the first block, the rest the second.
+struct FwdA2Args { BlockFwdAArgs x; BlockFwdAArgs y; int n1; };
+struct FwdB2Args { BlockFwdBArgs x; BlockFwdBArgs y; int n1; };
+template <int K1, int K2>
+__global__ __launch_bounds__(256) void block_fwd_a2_kernel(FwdA2Args k) {
+    extern __shared__ __attribute__((aligned(16))) float dyn[];
+    __shared__ BlockFwdAArgs sa;
+    const int n1 = k.n1;
+    if ((int)blockIdx.x < n1) {
+        const BlockFwdAArgs& a = raae::args_to_lds_at(&sa, (int)offsetof(FwdA2Args, x));
+        block_fwd_a_body<K1>(a, blockIdx.x, n1, dyn);
+    } else {
+        const BlockFwdAArgs& a = raae::args_to_lds_at(&sa, (int)offsetof(FwdA2Args, y));
+        block_fwd_a_body<K2>(a, blockIdx.x - n1, gridDim.x - n1, dyn);
+    }
+}
+template <int K1, int K2>
+__global__ __launch_bounds__(256) void block_fwd_b2_kernel(FwdB2Args k) {
+    extern __shared__ __attribute__((aligned(16))) float dyn[];
+    __shared__ BlockFwdBArgs sa;
+    const int n1 = k.n1;
+    if ((int)blockIdx.x < n1) {
+        const BlockFwdBArgs& a = raae::args_to_lds_at(&sa, (int)offsetof(FwdB2Args, x));
+        block_fwd_b_body<K1>(a, blockIdx.x, n1, dyn);
+    } else {
+        const BlockFwdBArgs& a = raae::args_to_lds_at(&sa, (int)offsetof(FwdB2Args, y));
+        block_fwd_b_body<K2>(a, blockIdx.x - n1, gridDim.x - n1, dyn);
+    }
+}
+
+// instances: encoder block i beside decoder block i of the 256-point networks; anything else: two launches
+#define RAAE_FWD_PAIRS(KERNEL) \
+    if (k1 == 0 && k2 == 3) { hipLaunchKernelGGL((KERNEL<0, 3>), grid, dim3(256), lds, (hipStream_t)stream, k); RAAE_LAUNCH_RET(); } \
+    if (k1 == 1 && k2 == 4) { hipLaunchKernelGGL((KERNEL<1, 4>), grid, dim3(256), lds, (hipStream_t)stream, k); RAAE_LAUNCH_RET(); } \
+    if (k1 == 2 && k2 == 5) { hipLaunchKernelGGL((KERNEL<2, 5>), grid, dim3(256), lds, (hipStream_t)stream, k); RAAE_LAUNCH_RET(); }
+
+extern "C" int raae_block_fwd_a2(const raae_block_fwd_a_t* x, const raae_block_fwd_a_t* y, int* nparts_x, int* nparts_y,
+                                 void* stream) {
+    static thread_local FwdA2Args k;
+    int g1, g2, k1, k2;
+    size_t l1, l2;
+    int rc = prep_block_fwd_a(x, k.x, g1, l1, k1);
+    if (rc) return rc;
+    rc = prep_block_fwd_a(y, k.y, g2, l2, k2);
+    if (rc) return rc;
+    if (nparts_x) *nparts_x = g1;
+    if (nparts_y) *nparts_y = g2;
+    k.n1 = g1;
+    const size_t lds = l1 > l2 ? l1 : l2;
+    const dim3 grid(g1 + g2);
+    RAAE_FWD_PAIRS(block_fwd_a2_kernel)
+    { const int kind = k1; const raae_block_fwd_a_t& a = k.x;
+      RAAE_LAUNCH_KIND(block_fwd_a_kernel, dim3(g1), dim3(256), l1, (hipStream_t)stream, a) }
+    { const int kind = k2; const raae_block_fwd_a_t& a = k.y;
+      RAAE_LAUNCH_KIND(block_fwd_a_kernel, dim3(g2), dim3(256), l2, (hipStream_t)stream, a) }
+    RAAE_LAUNCH_RET();
+}
+
+extern "C" int raae_block_fwd_b2(const raae_block_fwd_b_t* x, const raae_block_fwd_b_t* y, int* nparts_x, int* nparts_y,
+                                 void* stream) {
+    static thread_local FwdB2Args k;
+    int g1, g2, k1, k2;
+    size_t l1, l2;
+    int rc = prep_block_fwd_b(x, k.x, g1, l1, k1);
+    if (rc) return rc;
+    rc = prep_block_fwd_b(y, k.y, g2, l2, k2);
+    if (rc) return rc;
+    if (nparts_x) *nparts_x = g1;
+    if (nparts_y) *nparts_y = g2;
+    k.n1 = g1;
+    const size_t lds = l1 > l2 ? l1 : l2;
+    const dim3 grid(g1 + g2);
+    RAAE_FWD_PAIRS(block_fwd_b2_kernel)
+    { const int kind = k1; const raae_block_fwd_b_t& a = k.x;
+      RAAE_LAUNCH_KIND(block_fwd_b_kernel, dim3(g1), dim3(256), l1, (hipStream_t)stream, a) }
+    { const int kind = k2; const raae_block_fwd_b_t& a = k.y;
+      RAAE_LAUNCH_KIND(block_fwd_b_kernel, dim3(g2), dim3(256), l2, (hipStream_t)stream, a) }
+    RAAE_LAUNCH_RET();
+}
+#undef RAAE_FWD_PAIRS
 
 // checks + launch geometry of backward phase B (shared by raae_block_bwd_b and raae_block_bwd_b_wgrad)
 static int prep_block_bwd_b(const raae_block_bwd_b_t* in, raae_block_bwd_b_t& a, int& grid, size_t& lds, int& kind) {

@@ -712,11 +712,16 @@ class StepEngine:
         self._adam(P, "reconstruction", self._slab_notes)
         # ---- phase D: mutual information (:175-186)
         self._begin_phase(record)
-        with self.aux_branch():                     # result unused by the reference too (BN stats + RNG):
-            enc.forward(E, P.spec, P.m_enc[3])      # beside the decoder forward, which only needs z_sample
         z_s = tape.view(P.z_sample, b, ns)
-        out = dec.forward(D, z_s, P.m_dec[2])
-        self.join_aux()
+        if not self._branch and hasattr(enc, "forward_steps"):
+            # the encoder forward whose result the reference does not use (BN stats + RNG only) and the decoder
+            # forward, which only needs z_sample, in lockstep: one launch per pair of block kernels
+            _, out = enc.forward_pair(enc.forward_steps(E, P.spec, P.m_enc[3]), dec.forward_steps(D, z_s, P.m_dec[2]))
+        else:
+            with self.aux_branch():                 # ... or on the auxiliary stream, beside the decoder forward
+                enc.forward(E, P.spec, P.m_enc[3])
+            out = dec.forward(D, z_s, P.m_dec[2])
+            self.join_aux()
         z_rec = enc.forward(E, out, P.m_enc[4])
         n = ops.mse_fwd_bwd(z_rec, z_s, b * ns, P.lpart, P.dstyles)
         ops.loss_finalize(P.lpart, n, 1.0, lo, 3, 5)

@@ -163,6 +163,50 @@ class CompactNet:
 
     # ------------------------------------------------------------------ forward
     def forward(self, ws, x, masks, train=True):
+        """One forward pass, every launch on its own."""
+        steps = self.forward_steps(ws, x, masks, train)
+        try:
+            kind, args, nbytes = next(steps)
+            while True:
+                if kind == "a":
+                    n = self.eng.probe_launch("block_fwd_a", nbytes, lambda: ops.block_fwd_a(args))
+                else:
+                    n = ops.block_fwd_b(args)
+                kind, args, nbytes = steps.send(n)
+        except StopIteration as done:
+            return done.value
+
+    @staticmethod
+    def forward_pair(first, second):
+        """Two independent forward passes (``forward_steps`` generators, the ENCODER's first) in lockstep: while both
+        are at the same phase of a fused block the two kernels share one launch (raae_block_fwd_a2 / _b2).
+        Returns the two outputs."""
+        gens, cur, out = [first, second], [None, None], [None, None]
+        for j in (0, 1):
+            try:
+                cur[j] = next(gens[j])
+            except StopIteration as done:
+                out[j], gens[j] = done.value, None
+
+        def advance(j, n):
+            try:
+                cur[j] = gens[j].send(n)
+            except StopIteration as done:
+                out[j], gens[j], cur[j] = done.value, None, None
+        while gens[0] is not None or gens[1] is not None:
+            if gens[0] is not None and gens[1] is not None and cur[0][0] == cur[1][0]:
+                n1, n2 = ops.block_fwd_pair(cur[0][0], cur[0][1], cur[1][1])
+                advance(0, n1)
+                advance(1, n2)
+                continue
+            j = 0 if gens[0] is not None else 1
+            kind, args, _ = cur[j]
+            advance(j, ops.block_fwd_a(args) if kind == "a" else ops.block_fwd_b(args))
+        return out[0], out[1]
+
+    def forward_steps(self, ws, x, masks, train=True):
+        """Generator form of the forward pass: yields ``(phase, args, algorithmic bytes)`` at every fused-block
+        launch and expects the launch's partial-row count back; everything else is launched inline."""
         b = ws.b
         X, pX, nX = x, None, 0                # block input (raw), statistics of it
         for i, (k, w) in enumerate(zip(self.blocks, ws.blk)):
@@ -182,8 +226,8 @@ class CompactNet:
                                   (k.Cout * k.Lout if k.cvs is not None else 0) + k.Cin * k.E + k.Cin * k.Lout) + \
                     4 * (m.conv1.weight.numel() + m.fc1.weight.numel() + m.fc2.weight.numel() +
                          (m.conv_short.weight.numel() if k.cvs is not None else 0))
-                n1 = self.eng.probe_launch("block_fwd_a", nbytes, lambda: ops.block_fwd_a(
-                    vR(True), mask_i, b, k, m, w.T1, w.Sh, w.E1, w.E2, w.pT1, w.pE2 if k.cve is not None else None))
+                n1 = yield ("a", ops.block_fwd_a_args(vR(True), mask_i, b, k, m, w.T1, w.Sh, w.E1, w.E2, w.pT1,
+                                                      w.pE2 if k.cve is not None else None), nbytes)
                 w.nT1 = w.nE2 = n1
                 v1 = ops.make_view(w.T1, m.relu1.weight, self._bn(m.bn2, w.pT1, w.nT1, b * k.L1, train, True))
                 if k.cve is not None:
@@ -191,8 +235,8 @@ class CompactNet:
                                         self._bn(m.bn_excit, w.pE2, w.nE2, b * k.Lout, train, True))
                 else:
                     ve2 = ops.make_view(w.E2, m.relu_excit_2.weight)
-                w.nY = ops.block_fwd_b(v1, ve2, vR(False) if k.cvs is None else None, b, k, m, w.Sh, w.T2, w.E3, w.Y,
-                                       w.pY)
+                w.nY = yield ("b", ops.block_fwd_b_args(v1, ve2, vR(False) if k.cvs is None else None, b, k, m, w.Sh,
+                                                        w.T2, w.E3, w.Y, w.pY), 0)
                 X, pX, nX = w.Y, w.pY, w.nY
                 continue
             w.nT1 = ops.conv_fwd(vR(True), b, k.cv1, m.conv1.weight, m.conv1.bias, w.T1, OUT_STATS_PRELU,

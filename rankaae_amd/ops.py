@@ -302,8 +302,8 @@ def _p(t):
     return t.data_ptr() if t is not None else None
 
 
-def block_fwd_a(view_in, mask, B, k, m, T1, Sh, E1, E2, pT1, pE2):
-    """Fused forward phase A of a residual block (``k``: nets_conv.Block, ``m``: its nn.Module)."""
+def block_fwd_a_args(view_in, mask, B, k, m, T1, Sh, E1, E2, pT1, pE2):
+    """``raae_block_fwd_a_t`` of a residual block (``k``: nets_conv.Block, ``m``: its nn.Module)."""
     a = _lib.BlockFwdAT()
     a.inp, a.mask, a.B = view_in, _p(mask), B
     a.Cin, a.Cout, a.Lin, a.L1, a.Lout, a.E = k.Cin, k.Cout, k.Lin, k.L1, k.Lout, k.E
@@ -316,12 +316,25 @@ def block_fwd_a(view_in, mask, B, k, m, T1, Sh, E1, E2, pT1, pE2):
     a.wf1, a.bf1, a.se1 = _p(m.fc1.weight), _p(m.fc1.bias), _p(m.relu_excit_1.weight)
     a.wf2, a.bf2, a.se2 = _p(m.fc2.weight), _p(m.fc2.bias), _p(m.relu_excit_2.weight)
     a.T1, a.Sh, a.E1, a.E2, a.pT1, a.pE2 = _p(T1), _p(Sh), _p(E1), _p(E2), _p(pT1), _p(pE2)
+    return a
+
+
+def block_fwd_a(a):
+    """Fused forward phase A of a residual block; returns the number of partial-statistic rows written."""
     n = C.c_int(0)
     check(_lib.load().raae_block_fwd_a(C.byref(a), C.byref(n), _stream()), "raae_block_fwd_a")
     return n.value
 
 
-def block_fwd_b(vT1, vE2, vR, B, k, m, Sh, T2, E3, Y, pY):
+def block_fwd_pair(kind, x, y):
+    """Phase ``kind`` ("a" / "b") of two independent blocks in one launch; returns both row counts."""
+    n1, n2 = C.c_int(0), C.c_int(0)
+    fn = _lib.load().raae_block_fwd_a2 if kind == "a" else _lib.load().raae_block_fwd_b2
+    check(fn(C.byref(x), C.byref(y), C.byref(n1), C.byref(n2), _stream()), f"raae_block_fwd_{kind}2")
+    return n1.value, n2.value
+
+
+def block_fwd_b_args(vT1, vE2, vR, B, k, m, Sh, T2, E3, Y, pY):
     a = _lib.BlockFwdBT()
     a.vT1, a.vE2 = vT1, vE2
     if vR is not None:
@@ -337,6 +350,10 @@ def block_fwd_b(vT1, vE2, vR, B, k, m, Sh, T2, E3, Y, pY):
         a.Sh, a.ss = _p(Sh), _p(m.relu_short.weight)
     a.w2, a.b2, a.slope2 = _p(m.conv2.weight), _p(m.conv2.bias), _p(m.relu2.weight)
     a.T2, a.E3, a.Y, a.pY = _p(T2), _p(E3), _p(Y), _p(pY)
+    return a
+
+
+def block_fwd_b(a):
     n = C.c_int(0)
     check(_lib.load().raae_block_fwd_b(C.byref(a), C.byref(n), _stream()), "raae_block_fwd_b")
     return n.value
