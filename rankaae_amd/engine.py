@@ -684,10 +684,15 @@ class StepEngine:
         lo = self.loss_out
         # trainer.py:113-114
         styles = enc.forward(E, P.spec, P.m_enc[0])
-        # the reference discards this decoder output (BatchNorm statistics and RNG draws are its only effects):
-        # it runs beside phase A, which touches neither the decoder nor `styles`
-        with self.aux_branch():
-            dec.forward(D, styles, P.m_dec[0])
+        # The reference discards this decoder output (BatchNorm statistics and RNG draws are its only effects).
+        # Serial chain: it is deferred to phase B, where it runs in lockstep with the encoder forward (one launch
+        # per pair of block kernels) -- phase A updates neither the decoder nor, before that forward's last
+        # kernel, `styles`, so the results are bit for bit those of running it here
+        # (tests/test_engine_gpu.py::test_paired_forwards_change_nothing).  Branched graph: beside phase A.
+        pair = (not self._branch) and hasattr(enc, "forward_steps") and bool(c.get("pair_unused_forwards", True))
+        if not pair:
+            with self.aux_branch():
+                dec.forward(D, styles, P.m_dec[0])
         # ---- phase A: adversarial (trainer.py:117-127)
         self._begin_phase(record)
         dst = self.disc.forward_backward(P.disc, P.sl_disc, styles, lo[0:1])
@@ -696,7 +701,10 @@ class StepEngine:
         self._adam(P, "adversarial", self._slab_notes)
         # ---- phase B: rank correlation (:153-161)
         self._begin_phase(record)
-        styles = enc.forward(E, P.spec, P.m_enc[1])
+        if pair:
+            styles, _ = enc.forward_pair(enc.forward_steps(E, P.spec, P.m_enc[1]), dec.forward_steps(D, styles, P.m_dec[0]))
+        else:
+            styles = enc.forward(E, P.spec, P.m_enc[1])
         ops.rank_loss_fwd_bwd(P.aux, self.n_aux, styles, ns, b, self.n_aux, c["kendall_activation"], P.rank_work,
                               lo[1:2], P.dstyles)
         enc.backward(E, P.spec, P.m_enc[1], P.dstyles)
@@ -713,7 +721,7 @@ class StepEngine:
         # ---- phase D: mutual information (:175-186)
         self._begin_phase(record)
         z_s = tape.view(P.z_sample, b, ns)
-        if not self._branch and hasattr(enc, "forward_steps"):
+        if pair:
             # the encoder forward whose result the reference does not use (BN stats + RNG only) and the decoder
             # forward, which only needs z_sample, in lockstep: one launch per pair of block kernels
             _, out = enc.forward_pair(enc.forward_steps(E, P.spec, P.m_enc[3]), dec.forward_steps(D, z_s, P.m_dec[2]))
