@@ -208,7 +208,8 @@ int raae_conv_fwd(const raae_view_t* in, int B, const raae_conv_t* cv, const flo
 int raae_conv_bwd_data(const raae_grad_t* go, int B, const raae_conv_t* cv, const float* w, const raae_view_t* in,
                        float* din, int accumulate, double* din_partials, int* din_nparts, void* stream);
 /* parameter gradients: dw, dbias (same layouts as w/bias) and dslope [Cout] (may be NULL) as *nslab
- * fixed-order slabs (slab s at ptr + s*slab_stride), summed by raae_adam_step. */
+ * fixed-order slabs (slab s at ptr + s*slab_stride, *nslab <= RAAE_MAX_PARTS: size the buffer for that), summed
+ * by raae_adam_step. */
 int raae_conv_bwd_weight(const raae_grad_t* go, int B, const raae_conv_t* cv, const raae_view_t* in,
                          float* dw, float* dbias, float* dslope, long slab_stride, int* nslab, void* stream);
 

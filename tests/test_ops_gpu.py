@@ -471,7 +471,7 @@ def test_conv_family_fwd_bwd(kind, B, Cin, Lin, cfg):
     bn_out = ops.make_bn(pout, nout, B * Lout)
     go = ops.make_grad(dev(r["G"]), raw=out, slope=sOd, bn=bn_out, g_partials=gp.to(DEV), g_nparts=2)
     nwp, stride = (w.numel() + 63) // 64 * 64, (w.numel() + 63) // 64 * 64 + 128
-    slabs = torch.zeros(64, stride, device=DEV)
+    slabs = torch.zeros(_lib.RAAE_MAX_PARTS, stride, device=DEV)
     dwv, dbv, dsv = slabs[0, 0:], slabs[0, nwp:], slabs[0, nwp + 64:]
     din = torch.full((B, Cin, Lin), 0.5, device=DEV)
     pdin = torch.zeros(_lib.RAAE_MAX_PARTS, Cin, 2, dtype=torch.float64, device=DEV)
