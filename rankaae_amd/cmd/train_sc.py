@@ -3,8 +3,9 @@
 and log files as the reference's ``sc/cmd/train_sc.py:105-157`` (``training/job_<k>/{messages.txt,
 losses.csv,final.pt}``, ``main_process_message.txt``), with the training itself on the MI355X HIP
 engine.  The ipyparallel engine farm (``train_sc.py:19-45``) becomes one worker process per visible GPU:
-trial ``k`` runs on worker ``k mod n`` (``RANKAAE_TRIAL_WORKERS`` overrides ``n``; on ONE GPU trials run back
-to back, because processes sharing a GPU only time-slice it -- DESIGN.md section 8).  When launched under
+trial ``k`` runs on worker ``k mod n`` and worker ``w`` uses GPU ``w mod ngpus`` (``RANKAAE_TRIAL_WORKERS``
+overrides ``n``; the config key ``trials_per_gpu`` puts several workers on each GPU, which scales to ~2.8x at 4 --
+DESIGN.md section 8).  When launched under
 ``torch.distributed.run`` (WORLD_SIZE > 1) every trial instead trains data-parallel over RCCL
 (``rankaae_amd.parallel``)."""
 import argparse
@@ -67,7 +68,12 @@ def run_trials(trials, work_dir, train_config, verbose, data_file, timeout, logg
     nworkers = 1
     if world == 1 and trials > 1:
         # device_count() does not initialise the GPU, so the workers can still be spawned after it
-        nworkers = int(os.environ.get("RANKAAE_TRIAL_WORKERS", torch.cuda.device_count()))
+        # `trials_per_gpu` (config key, or RANKAAE_TRIALS_PER_GPU): worker processes that share one GPU.  At batches
+        # below 2048 rows a trial's step is one serial chain of small kernels, and such chains of different
+        # processes overlap on the chip: measured on one MI355X at B=256, conv networks: 727 steps/s alone,
+        # 2 x 657, 4 x 509 (2035 in total), 6 workers 2225 in total.
+        per_gpu = int(os.environ.get("RANKAAE_TRIALS_PER_GPU", train_config.get("trials_per_gpu", 1)))
+        nworkers = int(os.environ.get("RANKAAE_TRIAL_WORKERS", torch.cuda.device_count() * max(1, per_gpu)))
         nworkers = max(1, min(nworkers, trials))
     if nworkers == 1:
         return [run_training(k, work_dir, train_config, verbose, data_file, timeout, logger) for k in range(trials)], 1
