@@ -63,6 +63,15 @@ int raae_dense_fwd(const float* x, int B, int K, int in_kind, const float* slope
                    const float* mask, const float* w, const float* bias, int N, float* z, int out_kind,
                    const float* out_slope, double* out_partials, int* out_nparts, void* stream);
 
+/* Two raae_dense_fwd calls that do not depend on each other (a layer of the encoder and a layer of the decoder,
+ * while the forward chain the reference discards runs beside one that is needed) in ONE launch.  The struct holds
+ * raae_dense_fwd's arguments; has_bn = 0 stands for bn == NULL. */
+typedef struct {
+    const float* x; int B, K, in_kind; const float* slope; int has_bn; raae_bn_t bn; const float* mask;
+    const float* w; const float* bias; int N; float* z; int out_kind; const float* out_slope; double* out_partials;
+} raae_dense_fwd_t;
+int raae_dense_fwd2(const raae_dense_fwd_t* p, const raae_dense_fwd_t* q, int* nparts_p, int* nparts_q, void* stream);
+
 /* how the gradient w.r.t. this layer's raw output z is obtained in the prologue */
 enum { RAAE_G_DIRECT = 0,        /* g is dL/dz                                                  */
        RAAE_G_SOFTPLUS = 1,      /* g is dL/d softplus(z); `zout` holds softplus(z)             */
@@ -354,7 +363,7 @@ int raae_event_destroy(void* ev);
 int raae_stream_sync(void* stream);
 const char* raae_error_string(int code);
 int raae_device_info(int* cu_count, int* lds_bytes, char* name, int name_len);
-#define RAAE_ABI_VERSION 6
+#define RAAE_ABI_VERSION 7
 int raae_abi_version(void);
 /* First 16 hex digits of sha256 over include/rankaae_hip.h + csrc/raae_*.{h,inc,hip} at build time
  * (build.sh); the Python loader recomputes it and refuses a library built from other sources. */

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librankaae_hip.so")
 
 RAAE_MAX_PARTS = 512
-ABI_VERSION = 6
+ABI_VERSION = 7
 IN_NONE, IN_PRELU_BN_DROP, IN_PRELU_DROP = 0, 1, 2
 OUT_RAW, OUT_STATS_PRELU, OUT_STATS_RAW, OUT_SOFTPLUS, OUT_RELU = 0, 1, 2, 3, 4
 G_DIRECT, G_SOFTPLUS, G_PRELU_BN, G_PRELU, G_RELU = 0, 1, 2, 3, 4
@@ -20,6 +20,14 @@ class BnT(C.Structure):
     _fields_ = [("partials", C.c_void_p), ("nparts", C.c_int), ("count", C.c_float),
                 ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
                 ("momentum", C.c_float), ("eps", C.c_float), ("update_running", C.c_int)]
+
+
+class DenseFwdT(C.Structure):
+    """``raae_dense_fwd_t``"""
+    _fields_ = [("x", C.c_void_p), ("B", C.c_int), ("K", C.c_int), ("in_kind", C.c_int), ("slope", C.c_void_p),
+                ("has_bn", C.c_int), ("bn", BnT), ("mask", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p),
+                ("N", C.c_int), ("z", C.c_void_p), ("out_kind", C.c_int), ("out_slope", C.c_void_p),
+                ("out_partials", C.c_void_p)]
 
 
 class ViewT(C.Structure):
@@ -137,6 +145,7 @@ SIGNATURES = {
     "raae_grad_materialize": (_I, [_PG, _I, _I, _I, _P, _I, _P, _L, _PI, _P]),
     "raae_block_fwd_a": (_I, [C.POINTER(BlockFwdAT), _PI, _P]),
     "raae_block_fwd_b": (_I, [C.POINTER(BlockFwdBT), _PI, _P]),
+    "raae_dense_fwd2": (_I, [C.POINTER(DenseFwdT), C.POINTER(DenseFwdT), _PI, _PI, _P]),
     "raae_block_fwd_a2": (_I, [C.POINTER(BlockFwdAT), C.POINTER(BlockFwdAT), _PI, _PI, _P]),
     "raae_block_fwd_b2": (_I, [C.POINTER(BlockFwdBT), C.POINTER(BlockFwdBT), _PI, _PI, _P]),
     "raae_block_bwd_b": (_I, [C.POINTER(BlockBwdBT), _PI, _P]),

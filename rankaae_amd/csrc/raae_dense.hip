@@ -78,16 +78,17 @@ __device__ __forceinline__ void stage_rows(float* Xs, int pitch, const float* x,
 
 // dynamic LDS: s_mean[K4] s_rstd[K4] s_slope[K4] | Xs[16][pitch].  The wave's 16 output columns of W
 // stay in registers (KQ floats per lane = the B operands of all K/4 MFMA steps) across its row tiles.
+// (bx, by) of a (gx, *) grid: the workgroup's tile / column-block index (the whole grid of dense_fwd_kernel, one of
+// the two ranges of dense_fwd2_kernel)
 template <int KQ>
-__global__ __launch_bounds__(256) void dense_fwd_kernel(DenseFwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void dense_fwd_body(const DenseFwdArgs& a, const int bx, const int by, const int gx, float* smem) {
     const int K4 = (a.K + 3) & ~3;
     float* s_mean = smem;
     float* s_rstd = s_mean + K4;
     float* s_slope = s_rstd + K4;
     float* Xs = s_slope + K4;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int col = blockIdx.y * 64 + wv * 16 + (lane & 15);
+    const int col = by * 64 + wv * 16 + (lane & 15);
 
     float wreg[KQ];
 #pragma unroll
@@ -98,9 +99,9 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(DenseFwdArgs a) {
     if (a.in_kind == RAAE_IN_PRELU_BN_DROP) {
         if (a.K <= 64) {            // wave-per-statistic pass (raae_common.h), as in the conv kernels
             const raae::StatJob jobs[1] = {raae::stat_job_bn(a.bn, a.K, s_mean, s_rstd, true)};
-            raae::stat_jobs<1>(jobs, blockIdx.x == 0 && blockIdx.y == 0);
+            raae::stat_jobs<1>(jobs, bx == 0 && by == 0);
         } else {
-            raae::bn_prologue(a.bn, a.K, s_mean, s_rstd, blockIdx.x == 0 && blockIdx.y == 0);
+            raae::bn_prologue(a.bn, a.K, s_mean, s_rstd, bx == 0 && by == 0);
         }
     }
     if (a.in_kind != RAAE_IN_NONE)
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(DenseFwdArgs a) {
     double s_acc = 0.0, q_acc = 0.0;
     const float* xa = Xs + (lane & 15) * a.pitch + (lane >> 4);
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int tile = bx; tile < ntiles; tile += gx) {
         const int row0 = tile << 4;
         stage_rows(Xs, a.pitch, a.x, a.mask, row0, a.B, a.K, K4, a.in_kind, s_slope, s_mean, s_rstd);
         __syncthreads();
@@ -146,9 +147,30 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(DenseFwdArgs a) {
         s_acc += __shfl_xor(s_acc, 16, 64); q_acc += __shfl_xor(q_acc, 16, 64);
         s_acc += __shfl_xor(s_acc, 32, 64); q_acc += __shfl_xor(q_acc, 32, 64);
         if (lane < 16 && col < a.N) {
-            double* p = a.out_partials + ((size_t)blockIdx.x * a.N + col) * 2;
+            double* p = a.out_partials + ((size_t)bx * a.N + col) * 2;
             p[0] = s_acc; p[1] = q_acc;
         }
+    }
+}
+
+template <int KQ>
+__global__ __launch_bounds__(256) void dense_fwd_kernel(DenseFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    dense_fwd_body<KQ>(a, blockIdx.x, blockIdx.y, gridDim.x, smem);
+}
+
+// Two independent layers (one of the encoder, one of the decoder: the forward chain whose result the reference
+// discards beside one that is needed) in ONE launch: workgroups [0, n1) run the first, the rest the second.
+struct DenseFwd2Args { DenseFwdArgs x; DenseFwdArgs y; int n1; int gx1; int gx2; };
+template <int Q1, int Q2>
+__global__ __launch_bounds__(256) void dense_fwd2_kernel(DenseFwd2Args k) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int b = blockIdx.x;
+    if (b < k.n1) {
+        dense_fwd_body<Q1>(k.x, b % k.gx1, b / k.gx1, k.gx1, smem);
+    } else {
+        b -= k.n1;
+        dense_fwd_body<Q2>(k.y, b % k.gx2, b / k.gx2, k.gx2, smem);
     }
 }
 
@@ -380,16 +402,15 @@ int pick_grid(int B) {
 
 }  // namespace
 
-extern "C" int raae_dense_fwd(const float* x, int B, int K, int in_kind, const float* slope, const raae_bn_t* bn,
-                              const float* mask, const float* w, const float* bias, int N, float* z, int out_kind,
-                              const float* out_slope, double* out_partials, int* out_nparts, void* stream) {
+static int prep_dense_fwd(const float* x, int B, int K, int in_kind, const float* slope, const raae_bn_t* bn,
+                          const float* mask, const float* w, const float* bias, int N, float* z, int out_kind,
+                          const float* out_slope, double* out_partials, DenseFwdArgs& a, dim3& grid, size_t& lds, int& kq) {
     RAAE_CHECK_ARG(x && w && bias && z && B > 0 && K > 0 && N > 0 && K <= 512);
     RAAE_CHECK_ARG(in_kind >= 0 && in_kind <= 2 && out_kind >= 0 && out_kind <= 4);
     RAAE_CHECK_ARG(in_kind == RAAE_IN_NONE || slope);
     RAAE_CHECK_ARG(in_kind != RAAE_IN_PRELU_BN_DROP || (bn && (bn->partials || (bn->running_mean && bn->running_var))));
     RAAE_CHECK_ARG(!(out_kind == RAAE_OUT_STATS_PRELU) || out_slope);
     RAAE_CHECK_ARG(!(out_kind == RAAE_OUT_STATS_PRELU || out_kind == RAAE_OUT_STATS_RAW) || out_partials);
-    DenseFwdArgs a;
     a.x = x; a.B = B; a.K = K; a.in_kind = in_kind; a.slope = slope; a.mask = mask;
     if (bn) a.bn = *bn; else { raae_bn_t z0 = {}; a.bn = z0; }
     RAAE_CHECK_ARG(a.bn.nparts >= 0 && a.bn.nparts <= RAAE_MAX_PARTS);
@@ -398,14 +419,61 @@ extern "C" int raae_dense_fwd(const float* x, int B, int K, int in_kind, const f
     const int K4 = (K + 3) & ~3;
     RAAE_CHECK_ARG(K4 <= 512 && (in_kind != RAAE_IN_PRELU_BN_DROP || K <= 256));
     a.pitch = K4 + 2;
-    const size_t lds = sizeof(float) * (3 * (size_t)K4 + 16 * (size_t)a.pitch);
-    dim3 grid(pick_grid(B), (N + 63) / 64);
-    if (out_nparts) *out_nparts = (int)grid.x;
-    hipStream_t st = (hipStream_t)stream;
-    if (K4 <= 16) hipLaunchKernelGGL(dense_fwd_kernel<4>, grid, dim3(256), lds, st, a);
-    else if (K4 <= 64) hipLaunchKernelGGL(dense_fwd_kernel<16>, grid, dim3(256), lds, st, a);
-    else if (K4 <= 256) hipLaunchKernelGGL(dense_fwd_kernel<64>, grid, dim3(256), lds, st, a);
+    lds = sizeof(float) * (3 * (size_t)K4 + 16 * (size_t)a.pitch);
+    grid = dim3(pick_grid(B), (N + 63) / 64);
+    kq = K4 <= 16 ? 4 : K4 <= 64 ? 16 : K4 <= 256 ? 64 : 128;
+    return 0;
+}
+
+static void launch_dense_fwd(const DenseFwdArgs& a, dim3 grid, size_t lds, int kq, hipStream_t st) {
+    if (kq == 4) hipLaunchKernelGGL(dense_fwd_kernel<4>, grid, dim3(256), lds, st, a);
+    else if (kq == 16) hipLaunchKernelGGL(dense_fwd_kernel<16>, grid, dim3(256), lds, st, a);
+    else if (kq == 64) hipLaunchKernelGGL(dense_fwd_kernel<64>, grid, dim3(256), lds, st, a);
     else hipLaunchKernelGGL(dense_fwd_kernel<128>, grid, dim3(256), lds, st, a);
+}
+
+extern "C" int raae_dense_fwd(const float* x, int B, int K, int in_kind, const float* slope, const raae_bn_t* bn,
+                              const float* mask, const float* w, const float* bias, int N, float* z, int out_kind,
+                              const float* out_slope, double* out_partials, int* out_nparts, void* stream) {
+    DenseFwdArgs a;
+    dim3 grid;
+    size_t lds;
+    int kq;
+    const int rc = prep_dense_fwd(x, B, K, in_kind, slope, bn, mask, w, bias, N, z, out_kind, out_slope, out_partials,
+                                  a, grid, lds, kq);
+    if (rc) return rc;
+    if (out_nparts) *out_nparts = (int)grid.x;
+    launch_dense_fwd(a, grid, lds, kq, (hipStream_t)stream);
+    RAAE_LAUNCH_RET();
+}
+
+extern "C" int raae_dense_fwd2(const raae_dense_fwd_t* p, const raae_dense_fwd_t* q, int* nparts_p, int* nparts_q,
+                               void* stream) {
+    RAAE_CHECK_ARG(p && q);
+    DenseFwd2Args k;
+    dim3 g1, g2;
+    size_t l1, l2;
+    int q1, q2;
+    int rc = prep_dense_fwd(p->x, p->B, p->K, p->in_kind, p->slope, p->has_bn ? &p->bn : nullptr, p->mask, p->w, p->bias,
+                            p->N, p->z, p->out_kind, p->out_slope, p->out_partials, k.x, g1, l1, q1);
+    if (rc) return rc;
+    rc = prep_dense_fwd(q->x, q->B, q->K, q->in_kind, q->slope, q->has_bn ? &q->bn : nullptr, q->mask, q->w, q->bias,
+                        q->N, q->z, q->out_kind, q->out_slope, q->out_partials, k.y, g2, l2, q2);
+    if (rc) return rc;
+    if (nparts_p) *nparts_p = (int)g1.x;
+    if (nparts_q) *nparts_q = (int)g2.x;
+    hipStream_t st = (hipStream_t)stream;
+    k.n1 = (int)(g1.x * g1.y); k.gx1 = (int)g1.x; k.gx2 = (int)g2.x;
+    const dim3 grid(k.n1 + g2.x * g2.y);
+    const size_t lds = l1 > l2 ? l1 : l2;
+    // instances: the layer pairs of the 256-point dense networks (first layers 256 -> 64 beside 6 -> 64, then 64-wide
+    // layers beside each other); anything else: two launches
+    if (q1 == 64 && q2 == 4) hipLaunchKernelGGL((dense_fwd2_kernel<64, 4>), grid, dim3(256), lds, st, k);
+    else if (q1 == 16 && q2 == 16) hipLaunchKernelGGL((dense_fwd2_kernel<16, 16>), grid, dim3(256), lds, st, k);
+    else {
+        launch_dense_fwd(k.x, g1, l1, q1, st);
+        launch_dense_fwd(k.y, g2, l2, q2, st);
+    }
     RAAE_LAUNCH_RET();
 }
 

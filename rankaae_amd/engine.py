@@ -203,6 +203,42 @@ class FCNet:
         return ops.make_bn(None, 0, 0, p.bn.running_mean, p.bn.running_var, p.bn.momentum, p.bn.eps, False)
 
     def forward(self, ws, x, masks, train=True):
+        """One forward pass, every layer its own launch."""
+        steps = self.forward_steps(ws, x, masks, train)
+        try:
+            _, args, nbytes = next(steps)
+            while True:
+                _, args, nbytes = steps.send(self.eng.probe_launch("dense_fwd", nbytes,
+                                                                   lambda: ops.dense_fwd_struct(args)))
+        except StopIteration as done:
+            return done.value
+
+    @staticmethod
+    def forward_pair(first, second):
+        """Two independent forward passes (``forward_steps`` generators) in lockstep: layer i of both in one launch
+        (raae_dense_fwd2) while both have layers left.  Returns the two outputs."""
+        gens, cur, out = [first, second], [None, None], [None, None]
+
+        def advance(j, n):
+            try:
+                cur[j] = next(gens[j]) if n is None else gens[j].send(n)
+            except StopIteration as done:
+                out[j], gens[j], cur[j] = done.value, None, None
+        advance(0, None)
+        advance(1, None)
+        while gens[0] is not None or gens[1] is not None:
+            if gens[0] is not None and gens[1] is not None:
+                n1, n2 = ops.dense_fwd_pair(cur[0][1], cur[1][1])
+                advance(0, n1)
+                advance(1, n2)
+            else:
+                j = 0 if gens[0] is not None else 1
+                advance(j, ops.dense_fwd_struct(cur[j][1]))
+        return out[0], out[1]
+
+    def forward_steps(self, ws, x, masks, train=True):
+        """Generator form of the forward pass: yields ``("dense", args, algorithmic bytes)`` per layer and expects
+        the launch's partial-row count back."""
         eng, L, b = self.eng, self.layers, ws.b
         for i, l in enumerate(L):
             last = i == len(L) - 1
@@ -220,8 +256,8 @@ class FCNet:
             else:
                 out_kind, oslope = (OUT_RELU if self.final_relu else OUT_SOFTPLUS), None
             nbytes = 4 * (b * l.K * (2 if mask is not None else 1) + l.N * l.K + l.N + b * l.N)
-            ws.nparts[i] = eng.probe_launch("dense_fwd", nbytes, lambda: ops.dense_fwd(
-                xin, b, l.K, in_kind, slope, bn, mask, l.w, l.b, l.N, ws.z[i], out_kind, oslope, ws.part[i]))
+            ws.nparts[i] = yield ("dense", ops.dense_fwd_args(xin, b, l.K, in_kind, slope, bn, mask, l.w, l.b, l.N,
+                                                               ws.z[i], out_kind, oslope, ws.part[i]), nbytes)
         if self.kind == "enc":
             ops.style_bn_fwd(ws.z[-1], b, self.out_dim, self._bn_in(ws, len(L) - 1, train, True), ws.styles)
         if train:

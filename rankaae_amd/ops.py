@@ -51,6 +51,34 @@ def dense_fwd(x, B, K, in_kind, slope, bn, mask, w, bias, N, z, out_kind, out_sl
     return n.value
 
 
+def dense_fwd_args(x, B, K, in_kind, slope, bn, mask, w, bias, N, z, out_kind, out_slope=None, out_partials=None):
+    """``raae_dense_fwd_t`` holding the arguments of ``dense_fwd`` (for ``dense_fwd_pair``)."""
+    a = _lib.DenseFwdT()
+    a.x, a.B, a.K, a.in_kind, a.slope = _ptr(x), B, K, in_kind, _ptr(slope)
+    a.has_bn = 0 if bn is None else 1
+    if bn is not None:
+        a.bn = bn
+    a.mask, a.w, a.bias, a.N, a.z = _ptr(mask), _ptr(w), _ptr(bias), N, _ptr(z)
+    a.out_kind, a.out_slope, a.out_partials = out_kind, _ptr(out_slope), _ptr(out_partials, torch.float64)
+    return a
+
+
+def dense_fwd_struct(a):
+    """``dense_fwd`` from a ``raae_dense_fwd_t``."""
+    n = C.c_int(0)
+    check(_lib.load().raae_dense_fwd(a.x, a.B, a.K, a.in_kind, a.slope, C.byref(a.bn) if a.has_bn else None, a.mask, a.w,
+                                     a.bias, a.N, a.z, a.out_kind, a.out_slope, a.out_partials, C.byref(n), _stream()),
+          "raae_dense_fwd")
+    return n.value
+
+
+def dense_fwd_pair(p, q):
+    """Two independent dense layers in one launch; returns both partial-row counts."""
+    n1, n2 = C.c_int(0), C.c_int(0)
+    check(_lib.load().raae_dense_fwd2(C.byref(p), C.byref(q), C.byref(n1), C.byref(n2), _stream()), "raae_dense_fwd2")
+    return n1.value, n2.value
+
+
 def dense_bwd(g, g_kind, g_partials, g_nparts, zout, out_slope, out_bn, B, N, x, K, in_kind, slope, bn, mask, w,
               dw, db, dslope, slab_stride, dx=None, dx_partials=None):
     n = C.c_int(0)

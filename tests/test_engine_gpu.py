@@ -393,12 +393,13 @@ def test_one_row_batch_raises_like_the_reference():
     assert all(np.isfinite(v) for v in eng.losses().values())
 
 
-def test_paired_forwards_change_nothing():
+@pytest.mark.parametrize("case", ["compact_small", "fc_small"])
+def test_paired_forwards_change_nothing(case):
     """The two forward chains whose results the reference discards run in lockstep with a needed forward chain
     (one launch per pair of block kernels; the decoder one is deferred from before phase A into phase B).  Same
     arithmetic on the same operands: after three steps every parameter, BatchNorm running statistic, Adam moment
     and loss is bit for bit what the reference's schedule gives."""
-    g, cfg, spec, aux = load_case("compact_small")
+    g, cfg, spec, aux = load_case(case)
     out = []
     for pair in (False, True):
         eng = build_engine(dict(cfg, pair_unused_forwards=pair), g["model_seed"], spec, aux, rng_mode="philox")
