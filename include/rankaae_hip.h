@@ -126,6 +126,25 @@ int raae_style_metrics(const float* z, int n, int k, const double* a_coef, doubl
  * sweeps (sc/report/analysis.py:78-86, `decoder(con_c).reshape(n_spec, n_sampling, L).mean(axis=1)`). */
 int raae_group_mean(const float* x, int groups, int per, int L, float* out, void* stream);
 
+/* The adversarial branch of a step in ONE launch (DiscriminatorFC with three layers of width `hidden` = 64 and
+ * nstyle <= 16; sc/clustering/model.py:631-663, sc/utils/functions.py:109-132, model.py:8-22): input = [z_real ;
+ * styles] (+ sigma * noise), Linear/PReLU/Dropout x2, Linear, BCE-with-logits against ones (real rows) and zeros (fake
+ * rows), backward with all parameter gradients as *nslab slabs (<= 256), dstyles = -alpha[0] * dL/d(styles).
+ * Replaces raae_disc_input + 3 raae_dense_fwd + raae_bce_pair_fwd_bwd + 3 raae_dense_bwd + raae_scale_by_dev.
+ * mask1/mask2: dropout multipliers [n][hidden] or NULL; noise [n][ns] or NULL; partial: >= 256 doubles; ticket: one
+ * zero-initialised unsigned owned by the caller (the kernel leaves it at zero); loss: 1 float. */
+typedef struct {
+    const float* z_real; const float* styles; const float* noise; float sigma;
+    const float* mask1; const float* mask2;
+    const float* w1; const float* b1; const float* s1; const float* w2; const float* b2; const float* s2;
+    const float* w3; const float* b3; const float* alpha;
+    int n_real, n_fake, ns, hidden;
+    float* dw1; float* db1; float* ds1; float* dw2; float* db2; float* ds2; float* dw3; float* db3;
+    long slab_stride;
+    float* dstyles; double* partial; unsigned* ticket; float* loss;
+} raae_disc_fused_t;
+int raae_disc_fused(const raae_disc_fused_t* a, int* nslab, void* stream);
+
 /* recon_loss (functions.py:81-107): scale!=0 => "flexible target" branch.
  * partial: [>= grid] doubles (fixed-order loss partials); *nparts = grid. dout may be NULL. */
 int raae_recon_loss_fwd_bwd(const float* spec_in, const float* spec_out, int B, int L, int scale,
@@ -363,7 +382,7 @@ int raae_event_destroy(void* ev);
 int raae_stream_sync(void* stream);
 const char* raae_error_string(int code);
 int raae_device_info(int* cu_count, int* lds_bytes, char* name, int name_len);
-#define RAAE_ABI_VERSION 7
+#define RAAE_ABI_VERSION 8
 int raae_abi_version(void);
 /* First 16 hex digits of sha256 over include/rankaae_hip.h + csrc/raae_*.{h,inc,hip} at build time
  * (build.sh); the Python loader recomputes it and refuses a library built from other sources. */

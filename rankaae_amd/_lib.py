@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librankaae_hip.so")
 
 RAAE_MAX_PARTS = 512
-ABI_VERSION = 7
+ABI_VERSION = 8
 IN_NONE, IN_PRELU_BN_DROP, IN_PRELU_DROP = 0, 1, 2
 OUT_RAW, OUT_STATS_PRELU, OUT_STATS_RAW, OUT_SOFTPLUS, OUT_RELU = 0, 1, 2, 3, 4
 G_DIRECT, G_SOFTPLUS, G_PRELU_BN, G_PRELU, G_RELU = 0, 1, 2, 3, 4
@@ -28,6 +28,18 @@ class DenseFwdT(C.Structure):
                 ("has_bn", C.c_int), ("bn", BnT), ("mask", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p),
                 ("N", C.c_int), ("z", C.c_void_p), ("out_kind", C.c_int), ("out_slope", C.c_void_p),
                 ("out_partials", C.c_void_p)]
+
+
+class DiscFusedT(C.Structure):
+    """``raae_disc_fused_t``"""
+    _fields_ = [("z_real", C.c_void_p), ("styles", C.c_void_p), ("noise", C.c_void_p), ("sigma", C.c_float),
+                ("mask1", C.c_void_p), ("mask2", C.c_void_p),
+                ("w1", C.c_void_p), ("b1", C.c_void_p), ("s1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
+                ("s2", C.c_void_p), ("w3", C.c_void_p), ("b3", C.c_void_p), ("alpha", C.c_void_p),
+                ("n_real", C.c_int), ("n_fake", C.c_int), ("ns", C.c_int), ("hidden", C.c_int),
+                ("dw1", C.c_void_p), ("db1", C.c_void_p), ("ds1", C.c_void_p), ("dw2", C.c_void_p), ("db2", C.c_void_p),
+                ("ds2", C.c_void_p), ("dw3", C.c_void_p), ("db3", C.c_void_p), ("slab_stride", C.c_long),
+                ("dstyles", C.c_void_p), ("partial", C.c_void_p), ("ticket", C.c_void_p), ("loss", C.c_void_p)]
 
 
 class ViewT(C.Structure):
@@ -145,6 +157,7 @@ SIGNATURES = {
     "raae_grad_materialize": (_I, [_PG, _I, _I, _I, _P, _I, _P, _L, _PI, _P]),
     "raae_block_fwd_a": (_I, [C.POINTER(BlockFwdAT), _PI, _P]),
     "raae_block_fwd_b": (_I, [C.POINTER(BlockFwdBT), _PI, _P]),
+    "raae_disc_fused": (_I, [C.POINTER(DiscFusedT), _PI, _P]),
     "raae_dense_fwd2": (_I, [C.POINTER(DenseFwdT), C.POINTER(DenseFwdT), _PI, _PI, _P]),
     "raae_block_fwd_a2": (_I, [C.POINTER(BlockFwdAT), C.POINTER(BlockFwdAT), _PI, _PI, _P]),
     "raae_block_fwd_b2": (_I, [C.POINTER(BlockFwdBT), C.POINTER(BlockFwdBT), _PI, _PI, _P]),

@@ -312,6 +312,8 @@ class DiscNet:
         wmax = max(max(l.N, l.K) for l in self.layers)
         ws.dx = [torch.empty(ws.n, wmax, device=dev) for _ in range(2)]
         ws.dstyles = torch.empty(n_fake, self.nstyle, device=dev)
+        ws.partial = torch.zeros(256, dtype=torch.float64, device=dev)       # raae_disc_fused: loss partials
+        ws.ticket = torch.zeros(1, dtype=torch.int32, device=dev)           # ... and its arrival counter
         return ws
 
     def tape_slots(self, tape, n_real, n_fake, train):
@@ -339,6 +341,16 @@ class DiscNet:
         tape = eng.tape
         z_real = tape.view(sl.z_real, ws.n_real, self.nstyle)
         noise = tape.view(sl.noise, ws.n, self.nstyle) if train else None
+        if (train and len(L) == 3 and L[0].N == 64 and L[1].N == 64 and L[2].N == 1 and self.nstyle <= 16 and
+                eng.cfg.get("fused_discriminator", True)):
+            # the reference's discriminator shape: the whole branch (input, 3 layers forward, BCE, backward, gradient
+            # reversal) is one launch
+            masks = [tape.view(m[0], *m[1]) if m else None for m in sl.masks]
+            ns_ = ops.disc_fused(z_real, styles, noise, float(self.module.noise), masks[0], masks[1], L, eng.alpha_dev,
+                                 ws.n_real, ws.n_fake, self.nstyle, eng.gslab, eng.arena.n, ws.dstyles, ws.partial,
+                                 ws.ticket, loss_out)
+            eng.note_slabs([L[0].w, L[0].b, L[0].prelu.weight, L[1].w, L[1].b, L[1].prelu.weight, L[2].w, L[2].b], ns_)
+            return ws.dstyles
         ops.disc_input(z_real, styles, noise, float(self.module.noise), ws.n_real, ws.n_fake, self.nstyle, ws.x)
         masks = [tape.view(m[0], *m[1]) if (train and m) else None for m in sl.masks]
         for i, l in enumerate(L):

@@ -79,6 +79,28 @@ def dense_fwd_pair(p, q):
     return n1.value, n2.value
 
 
+def disc_fused(z_real, styles, noise, sigma, mask1, mask2, layers, alpha, n_real, n_fake, ns, gslab, slab_stride,
+               dstyles, partial, ticket, loss):
+    """The adversarial branch in one launch (``raae_disc_fused``); ``layers``: the three dense layers of the
+    discriminator (``w``, ``b``, ``prelu``); returns the slab count of the parameter gradients."""
+    l1, l2, l3 = layers
+    a = _lib.DiscFusedT()
+    a.z_real, a.styles, a.noise, a.sigma = z_real.data_ptr(), styles.data_ptr(), _p(noise), float(sigma)
+    a.mask1, a.mask2 = _p(mask1), _p(mask2)
+    a.w1, a.b1, a.s1 = l1.w.data_ptr(), l1.b.data_ptr(), l1.prelu.weight.data_ptr()
+    a.w2, a.b2, a.s2 = l2.w.data_ptr(), l2.b.data_ptr(), l2.prelu.weight.data_ptr()
+    a.w3, a.b3, a.alpha = l3.w.data_ptr(), l3.b.data_ptr(), alpha.data_ptr()
+    a.n_real, a.n_fake, a.ns, a.hidden = n_real, n_fake, ns, l1.N
+    a.dw1, a.db1, a.ds1 = gslab(l1.w).data_ptr(), gslab(l1.b).data_ptr(), gslab(l1.prelu.weight).data_ptr()
+    a.dw2, a.db2, a.ds2 = gslab(l2.w).data_ptr(), gslab(l2.b).data_ptr(), gslab(l2.prelu.weight).data_ptr()
+    a.dw3, a.db3 = gslab(l3.w).data_ptr(), gslab(l3.b).data_ptr()
+    a.slab_stride = slab_stride
+    a.dstyles, a.partial, a.ticket, a.loss = dstyles.data_ptr(), partial.data_ptr(), ticket.data_ptr(), loss.data_ptr()
+    n = C.c_int(0)
+    check(_lib.load().raae_disc_fused(C.byref(a), C.byref(n), _stream()), "raae_disc_fused")
+    return n.value
+
+
 def dense_bwd(g, g_kind, g_partials, g_nparts, zout, out_slope, out_bn, B, N, x, K, in_kind, slope, bn, mask, w,
               dw, db, dslope, slab_stride, dx=None, dx_partials=None):
     n = C.c_int(0)
