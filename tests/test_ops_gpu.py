@@ -587,3 +587,63 @@ def test_style_metrics_match_scipy(n, k):
     m.launch(dev(torch.from_numpy(z)))                        # fixed-order sums: bitwise repeatable
     W2, rho2 = m.read()
     assert np.array_equal(W, W2) and np.array_equal(rho, rho2)
+
+
+@pytest.mark.parametrize("n_real,n_fake,ns,drop", [(40, 23, 6, True), (256, 256, 6, True), (64, 36, 13, False),
+                                                   (4096, 4100, 6, True)])
+def test_disc_fused_matches_autograd(n_real, n_fake, ns, drop):
+    """raae_disc_fused (the adversarial branch in one launch) against torch autograd of the same computation:
+    [z_real; styles] + sigma*noise -> Linear/PReLU/Dropout x2 -> Linear -> BCE-with-logits(ones | zeros); loss,
+    every parameter gradient (fixed-order slab sum) and dstyles = -alpha * dL/dstyles."""
+    g = torch.Generator().manual_seed(n_real + ns)
+    n, H, sigma, alpha, p = n_real + n_fake, 64, 0.56, 0.37, 0.056
+    lin = [torch.nn.Linear(ns, H), torch.nn.Linear(H, H), torch.nn.Linear(H, 1)]
+    pre = [torch.nn.PReLU(H), torch.nn.PReLU(H)]
+    with torch.no_grad():
+        for q in pre:
+            q.weight.copy_(0.1 + 0.3 * torch.rand(H, generator=g))
+    z_real = torch.randn(n_real, ns, generator=g)
+    styles = torch.randn(n_fake, ns, generator=g).requires_grad_(True)
+    noise = torch.randn(n, ns, generator=g)
+    masks = [((torch.rand(n, H, generator=g) > p).float() / (1 - p)) if drop else None for _ in range(2)]
+    x = torch.cat([z_real, styles]) + sigma * noise
+    h = x
+    for i in range(2):
+        h = pre[i](lin[i](h))
+        if masks[i] is not None:
+            h = h * masks[i]
+    o = lin[2](h).squeeze(1)
+    loss = F.binary_cross_entropy_with_logits(o[:n_real], torch.ones(n_real)) + \
+        F.binary_cross_entropy_with_logits(o[n_real:], torch.zeros(n_fake))
+    loss.backward()
+
+    class L:
+        pass
+    layers = []
+    for i in range(3):
+        l = L()
+        l.w, l.b, l.N = dev(lin[i].weight.detach()), dev(lin[i].bias.detach()), lin[i].out_features
+        l.prelu = L()
+        l.prelu.weight = dev(pre[i].weight.detach()) if i < 2 else None
+        layers.append(l)
+    params = [layers[0].w, layers[0].b, layers[0].prelu.weight, layers[1].w, layers[1].b, layers[1].prelu.weight,
+              layers[2].w, layers[2].b]
+    offs, tot = {}, 0
+    for q in params:
+        offs[id(q)] = tot
+        tot += (q.numel() + 63) // 64 * 64
+    slabs = torch.zeros(256, tot, device=DEV)
+    dstyles = torch.empty(n_fake, ns, device=DEV)
+    out = torch.zeros(1, device=DEV)
+    nsl = ops.disc_fused(dev(z_real), dev(styles.detach()), dev(noise), sigma, dev(masks[0]) if drop else None,
+                         dev(masks[1]) if drop else None, layers, torch.tensor([alpha], device=DEV), n_real, n_fake, ns,
+                         lambda q: slabs[0, offs[id(q)]:], tot, dstyles, torch.zeros(256, dtype=torch.float64, device=DEV),
+                         torch.zeros(1, dtype=torch.int32, device=DEV), out)
+    assert 1 <= nsl <= 256
+    close(out, loss.detach().view(1), 1e-5, 1e-6, "loss")
+    close(dstyles, -alpha * styles.grad, 2e-4, 1e-7 + 2e-4 * float(styles.grad.abs().max()) * alpha, "dstyles")
+    ref = [lin[0].weight.grad, lin[0].bias.grad, pre[0].weight.grad, lin[1].weight.grad, lin[1].bias.grad,
+           pre[1].weight.grad, lin[2].weight.grad, lin[2].bias.grad]
+    for q, r, name in zip(params, ref, ["dw1", "db1", "ds1", "dw2", "db2", "ds2", "dw3", "db3"]):
+        got = slabs[:nsl, offs[id(q)]:offs[id(q)] + q.numel()].sum(0).view(r.shape)
+        close(got, r, 2e-4, 1e-7 + 2e-4 * float(r.abs().max()), name)
