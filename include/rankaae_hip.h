@@ -145,18 +145,25 @@ typedef struct {
 } raae_disc_fused_t;
 int raae_disc_fused(const raae_disc_fused_t* a, int* nslab, void* stream);
 
+/* Optional last argument of the three loss kernels below: finish the loss inside the kernel (the last workgroup to
+ * arrive adds the partials in index order: out[slot] = scale * sum, out[acc_slot] += it when acc_slot >= 0) instead of
+ * a raae_loss_finalize launch.  ticket: one zero-initialised unsigned owned by the caller, left at zero; NULL (or
+ * fin == NULL): the partials are left to the caller. */
+typedef struct { float scale; float* out; int slot; int acc_slot; unsigned* ticket; } raae_loss_fin_t;
+
 /* recon_loss (functions.py:81-107): scale!=0 => "flexible target" branch.
  * partial: [>= grid] doubles (fixed-order loss partials); *nparts = grid. dout may be NULL. */
 int raae_recon_loss_fwd_bwd(const float* spec_in, const float* spec_out, int B, int L, int scale,
-                            double* partial, int* nparts, float* dout, void* stream);
+                            double* partial, int* nparts, float* dout, const raae_loss_fin_t* fin, void* stream);
 
 /* smoothness_loss (functions.py:194-212, model.py:177-229): replicate pad, `ntaps`-tap
  * normalised Gaussian (taps given by the host), MSE(x, G x); gradient through both operands. */
 int raae_smooth_loss_fwd_bwd(const float* x, int B, int L, const float* taps, int ntaps,
-                             double* partial, int* nparts, float* dx, void* stream);
+                             double* partial, int* nparts, float* dx, const raae_loss_fin_t* fin, void* stream);
 
 /* nn.MSELoss (mutual_info_loss, functions.py:187-190): mean((a-b)^2), da = 2(a-b)/n. */
-int raae_mse_fwd_bwd(const float* a, const float* b, long n, double* partial, int* nparts, float* da, void* stream);
+int raae_mse_fwd_bwd(const float* a, const float* b, long n, double* partial, int* nparts, float* da,
+                     const raae_loss_fin_t* fin, void* stream);
 
 /* BCEWithLogitsLoss(real,1) + BCEWithLogitsLoss(fake,0), each mean-reduced over its
  * own count (functions.py:119-130).  logits [n_real + n_fake]; dlogits same shape. */
@@ -382,7 +389,7 @@ int raae_event_destroy(void* ev);
 int raae_stream_sync(void* stream);
 const char* raae_error_string(int code);
 int raae_device_info(int* cu_count, int* lds_bytes, char* name, int name_len);
-#define RAAE_ABI_VERSION 8
+#define RAAE_ABI_VERSION 9
 int raae_abi_version(void);
 /* First 16 hex digits of sha256 over include/rankaae_hip.h + csrc/raae_*.{h,inc,hip} at build time
  * (build.sh); the Python loader recomputes it and refuses a library built from other sources. */

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librankaae_hip.so")
 
 RAAE_MAX_PARTS = 512
-ABI_VERSION = 8
+ABI_VERSION = 9
 IN_NONE, IN_PRELU_BN_DROP, IN_PRELU_DROP = 0, 1, 2
 OUT_RAW, OUT_STATS_PRELU, OUT_STATS_RAW, OUT_SOFTPLUS, OUT_RELU = 0, 1, 2, 3, 4
 G_DIRECT, G_SOFTPLUS, G_PRELU_BN, G_PRELU, G_RELU = 0, 1, 2, 3, 4
@@ -40,6 +40,12 @@ class DiscFusedT(C.Structure):
                 ("dw1", C.c_void_p), ("db1", C.c_void_p), ("ds1", C.c_void_p), ("dw2", C.c_void_p), ("db2", C.c_void_p),
                 ("ds2", C.c_void_p), ("dw3", C.c_void_p), ("db3", C.c_void_p), ("slab_stride", C.c_long),
                 ("dstyles", C.c_void_p), ("partial", C.c_void_p), ("ticket", C.c_void_p), ("loss", C.c_void_p)]
+
+
+class LossFinT(C.Structure):
+    """``raae_loss_fin_t``"""
+    _fields_ = [("scale", C.c_float), ("out", C.c_void_p), ("slot", C.c_int), ("acc_slot", C.c_int),
+                ("ticket", C.c_void_p)]
 
 
 class ViewT(C.Structure):
@@ -138,9 +144,9 @@ SIGNATURES = {
     "raae_rank_loss_fwd_bwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "raae_style_metrics": (_I, [_P, _I, _I, _P, _P, _P, _P]),
     "raae_group_mean": (_I, [_P, _I, _I, _I, _P, _P]),
-    "raae_recon_loss_fwd_bwd": (_I, [_P, _P, _I, _I, _I, _P, _PI, _P, _P]),
-    "raae_smooth_loss_fwd_bwd": (_I, [_P, _I, _I, C.POINTER(C.c_float), _I, _P, _PI, _P, _P]),
-    "raae_mse_fwd_bwd": (_I, [_P, _P, _L, _P, _PI, _P, _P]),
+    "raae_recon_loss_fwd_bwd": (_I, [_P, _P, _I, _I, _I, _P, _PI, _P, C.POINTER(LossFinT), _P]),
+    "raae_smooth_loss_fwd_bwd": (_I, [_P, _I, _I, C.POINTER(C.c_float), _I, _P, _PI, _P, C.POINTER(LossFinT), _P]),
+    "raae_mse_fwd_bwd": (_I, [_P, _P, _L, _P, _PI, _P, C.POINTER(LossFinT), _P]),
     "raae_bce_pair_fwd_bwd": (_I, [_P, _I, _I, _P, _P, _P]),
     "raae_disc_input": (_I, [_P, _P, _P, _F, _I, _I, _I, _P, _P]),
     "raae_scale_by_dev": (_I, [_P, _P, _F, _L, _P, _P]),

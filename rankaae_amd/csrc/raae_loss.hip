@@ -206,8 +206,36 @@ __global__ __launch_bounds__(256) void rank_finalize_kernel(const RankWork* part
 
 // ------------------------------------------------------------------ reconstruction loss
 // functions.py:81-107.  One wave per row; L <= 1024.
+// Optional finalisation inside the loss kernel: after thread 0 has stored this workgroup's partial, the LAST workgroup
+// to arrive (ticket) adds all partials in index order and writes the loss -- what raae_loss_finalize does in a launch
+// of its own.  All threads call it; `f.ticket == NULL` leaves the partials to the caller.
+struct LossFin { float scale; float* out; int slot; int acc_slot; unsigned* ticket; };
+__device__ __forceinline__ void loss_fin_last_block(const LossFin& f, double* partial) {
+    __shared__ unsigned s_fin_last;
+    if (f.ticket == nullptr) return;
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_fin_last = atomicAdd(f.ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_fin_last && threadIdx.x == 0) {
+        __threadfence();
+        double t = 0.0;
+        for (unsigned i = 0; i < gridDim.x; ++i) t += ((volatile double*)partial)[i];
+        const float v = (float)(t * (double)f.scale);
+        f.out[f.slot] = v;
+        if (f.acc_slot >= 0) f.out[f.acc_slot] += v;
+        *f.ticket = 0u;
+    }
+}
+static LossFin make_fin(const raae_loss_fin_t* fin) {
+    LossFin f = {1.f, nullptr, 0, -1, nullptr};
+    if (fin && fin->ticket) { f.scale = fin->scale; f.out = fin->out; f.slot = fin->slot; f.acc_slot = fin->acc_slot; f.ticket = fin->ticket; }
+    return f;
+}
+
 __global__ __launch_bounds__(256) void recon_kernel(const float* x, const float* y, int B, int L, int scale,
-                                                    double* partial, float* dy) {
+                                                    double* partial, float* dy, LossFin fin) {
     __shared__ double shd[16];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double acc = 0.0;
@@ -238,6 +266,7 @@ __global__ __launch_bounds__(256) void recon_kernel(const float* x, const float*
     }
     const double t = raae::block_sum(acc, shd);
     if (threadIdx.x == 0) partial[blockIdx.x] = t;
+    loss_fin_last_block(fin, partial);
 }
 
 // ------------------------------------------------------------------ smoothness loss
@@ -250,7 +279,7 @@ struct Taps { float w[SM_MAXT]; int n; };
 // stay in scalar registers -- with a run-time count every tap was a scalar load from the kernarg segment with its
 // own wait (15.7 us for 256 rows; NT = 0 keeps that generic form).
 template <int NT>
-__global__ __launch_bounds__(256) void smooth_kernel(const float* x, int B, int L, Taps tp, double* partial, float* dx) {
+__global__ __launch_bounds__(256) void smooth_kernel(const float* x, int B, int L, Taps tp, double* partial, float* dx, LossFin fin) {
     const int ntap = NT > 0 ? NT : tp.n;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [4 waves][2][L]
     __shared__ double shd[16];
@@ -305,10 +334,11 @@ __global__ __launch_bounds__(256) void smooth_kernel(const float* x, int B, int 
     }
     const double t = raae::block_sum(acc, shd);
     if (threadIdx.x == 0) partial[blockIdx.x] = t;
+    loss_fin_last_block(fin, partial);
 }
 
 // ------------------------------------------------------------------ MSE (mutual-info loss)
-__global__ __launch_bounds__(256) void mse_kernel(const float* a, const float* b, long n, double* partial, float* da) {
+__global__ __launch_bounds__(256) void mse_kernel(const float* a, const float* b, long n, double* partial, float* da, LossFin fin) {
     __shared__ double shd[16];
     double acc = 0.0;
     const float inv = 1.f / (float)n;
@@ -319,6 +349,7 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* a, const float* b
     }
     const double t = raae::block_sum(acc, shd);
     if (threadIdx.x == 0) partial[blockIdx.x] = t / (double)n;
+    loss_fin_last_block(fin, partial);
 }
 
 // ------------------------------------------------------------------ BCE-with-logits pair
@@ -444,33 +475,34 @@ extern "C" int raae_rank_loss_fwd_bwd(const float* d, int ldd, const float* z, i
 }
 
 extern "C" int raae_recon_loss_fwd_bwd(const float* spec_in, const float* spec_out, int B, int L, int scale,
-                                       double* partial, int* nparts, float* dout, void* stream) {
-    RAAE_CHECK_ARG(spec_in && spec_out && partial && B > 0 && L > 0);
+                                       double* partial, int* nparts, float* dout, const raae_loss_fin_t* fin, void* stream) {
+    RAAE_CHECK_ARG(spec_in && spec_out && partial && B > 0 && L > 0 && (!fin || !fin->ticket || (fin->out && fin->slot >= 0)));
     const int g = grid_for(B, 4, RAAE_MAX_PARTS);
     if (nparts) *nparts = g;
-    hipLaunchKernelGGL(recon_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, spec_in, spec_out, B, L, scale, partial, dout);
+    hipLaunchKernelGGL(recon_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, spec_in, spec_out, B, L, scale, partial, dout, make_fin(fin));
     RAAE_LAUNCH_RET();
 }
 
 extern "C" int raae_smooth_loss_fwd_bwd(const float* x, int B, int L, const float* taps, int ntaps,
-                                        double* partial, int* nparts, float* dx, void* stream) {
-    RAAE_CHECK_ARG(x && taps && partial && B > 0 && L > 1 && ntaps >= 1 && ntaps <= SM_MAXT && (ntaps & 1) && L <= 4096);
+                                        double* partial, int* nparts, float* dx, const raae_loss_fin_t* fin, void* stream) {
+    RAAE_CHECK_ARG((!fin || !fin->ticket || (fin->out && fin->slot >= 0)) && x && taps && partial && B > 0 && L > 1 && ntaps >= 1 && ntaps <= SM_MAXT && (ntaps & 1) && L <= 4096);
     Taps tp; tp.n = ntaps;
     for (int i = 0; i < ntaps; ++i) tp.w[i] = taps[i];   // `taps` is a HOST pointer (17 floats)
     const int g = grid_for(B, 4, RAAE_MAX_PARTS);
     if (nparts) *nparts = g;
     if (ntaps == 17)
-        hipLaunchKernelGGL(smooth_kernel<17>, dim3(g), dim3(256), sizeof(float) * 8 * (size_t)L, (hipStream_t)stream, x, B, L, tp, partial, dx);
+        hipLaunchKernelGGL(smooth_kernel<17>, dim3(g), dim3(256), sizeof(float) * 8 * (size_t)L, (hipStream_t)stream, x, B, L, tp, partial, dx, make_fin(fin));
     else
-        hipLaunchKernelGGL(smooth_kernel<0>, dim3(g), dim3(256), sizeof(float) * 8 * (size_t)L, (hipStream_t)stream, x, B, L, tp, partial, dx);
+        hipLaunchKernelGGL(smooth_kernel<0>, dim3(g), dim3(256), sizeof(float) * 8 * (size_t)L, (hipStream_t)stream, x, B, L, tp, partial, dx, make_fin(fin));
     RAAE_LAUNCH_RET();
 }
 
-extern "C" int raae_mse_fwd_bwd(const float* a, const float* b, long n, double* partial, int* nparts, float* da, void* stream) {
-    RAAE_CHECK_ARG(a && b && partial && n > 0);
+extern "C" int raae_mse_fwd_bwd(const float* a, const float* b, long n, double* partial, int* nparts, float* da,
+                                const raae_loss_fin_t* fin, void* stream) {
+    RAAE_CHECK_ARG(a && b && partial && n > 0 && (!fin || !fin->ticket || (fin->out && fin->slot >= 0)));
     const int g = grid_for(n, 1024, RAAE_MAX_PARTS);
     if (nparts) *nparts = g;
-    hipLaunchKernelGGL(mse_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, a, b, n, partial, da);
+    hipLaunchKernelGGL(mse_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, a, b, n, partial, da, make_fin(fin));
     RAAE_LAUNCH_RET();
 }
 

@@ -649,6 +649,7 @@ class StepEngine:
         P.dspec = torch.empty(b, self.L, device=dev)
         P.dout = torch.empty(b, self.L, device=dev)
         P.lpart = torch.zeros(RAAE_MAX_PARTS, dtype=torch.float64, device=dev)
+        P.ticket = torch.zeros(1, dtype=torch.int32, device=dev)      # arrival counter of the in-kernel loss sums
         P.seg = {n: torch.zeros(self.arena.n // 64, dtype=torch.int16, device=dev) for n in OPT_NAMES}
         P.max_slab = {n: 0 for n in OPT_NAMES}
         P.graphs = {}
@@ -761,8 +762,8 @@ class StepEngine:
         self._begin_phase(record)
         styles = enc.forward(E, P.spec, P.m_enc[2])
         out = dec.forward(D, styles, P.m_dec[1])
-        n = ops.recon_loss_fwd_bwd(P.spec, out, b, self.L, c["use_flex_spec_target"], P.lpart, P.dout)
-        ops.loss_finalize(P.lpart, n, 1.0, lo, 2)
+        ops.recon_loss_fwd_bwd(P.spec, out, b, self.L, c["use_flex_spec_target"], P.lpart, P.dout,
+                               fin=(1.0, lo, 2, -1, P.ticket))
         left = dec.backward(D, styles, P.m_dec[1], P.dout, P.dstyles, keep_pending=True)
         enc.backward(E, P.spec, P.m_enc[2], P.dstyles, pending=left)
         self._adam(P, "reconstruction", self._slab_notes)
@@ -779,8 +780,7 @@ class StepEngine:
             out = dec.forward(D, z_s, P.m_dec[2])
             self.join_aux()
         z_rec = enc.forward(E, out, P.m_enc[4])
-        n = ops.mse_fwd_bwd(z_rec, z_s, b * ns, P.lpart, P.dstyles)
-        ops.loss_finalize(P.lpart, n, 1.0, lo, 3, 5)
+        ops.mse_fwd_bwd(z_rec, z_s, b * ns, P.lpart, P.dstyles, fin=(1.0, lo, 3, 5, P.ticket))
         left = enc.backward(E, out, P.m_enc[4], P.dstyles, P.dspec, keep_pending=True)
         dec.backward(D, z_s, P.m_dec[2], P.dspec, None, pending=left)
         self._adam(P, "mutual_info", self._slab_notes)
@@ -789,8 +789,7 @@ class StepEngine:
             self._begin_phase(record)
             styles = enc.forward(E, P.spec, P.m_enc[5])
             out = dec.forward(D, styles, P.m_dec[3])
-            n = ops.smooth_loss_fwd_bwd(out, b, self.L, self.taps, P.lpart, P.dout)
-            ops.loss_finalize(P.lpart, n, 1.0, lo, 4)
+            ops.smooth_loss_fwd_bwd(out, b, self.L, self.taps, P.lpart, P.dout, fin=(1.0, lo, 4, -1, P.ticket))
             dec.backward(D, styles, P.m_dec[3], P.dout, None)
             self._adam(P, "smoothness", self._slab_notes)
         self._slab_notes = None
@@ -1033,6 +1032,7 @@ class StepEngine:
             V.tape.finalize(dev)
             V.rank_work = torch.empty(ops.rank_loss_work_bytes(nv, self.n_aux), dtype=torch.uint8, device=dev)
             V.lpart = torch.zeros(RAAE_MAX_PARTS, dtype=torch.float64, device=dev)
+            V.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
             V.out = torch.zeros(8, device=dev)
             V.metrics = StyleMetrics(nv, ns, dev)
             self.plans[key] = V
@@ -1049,17 +1049,14 @@ class StepEngine:
                              self.seed ^ 0x5EED, self.rng_counter)
             z = self.enc.forward(V.enc, val_spec, None, train=False)
             out = self.dec.forward(V.dec, z, None, train=False)
-            n = ops.recon_loss_fwd_bwd(val_spec, out, nv, self.L, False, V.lpart, None)
-            ops.loss_finalize(V.lpart, n, 1.0, V.out, 2)
+            ops.recon_loss_fwd_bwd(val_spec, out, nv, self.L, False, V.lpart, None, fin=(1.0, V.out, 2, -1, V.ticket))
             ops.rank_loss_fwd_bwd(val_aux, self.n_aux, z, ns, nv, self.n_aux, c["kendall_activation"], V.rank_work,
                                   V.out[1:2], None)
-            n = ops.smooth_loss_fwd_bwd(out, nv, self.L, self.taps, V.lpart, None)
-            ops.loss_finalize(V.lpart, n, 1.0, V.out, 4)
+            ops.smooth_loss_fwd_bwd(out, nv, self.L, self.taps, V.lpart, None, fin=(1.0, V.out, 4, -1, V.ticket))
             z_s = V.tape.view(V.z_sample, nv, ns)
             out2 = self.dec.forward(V.dec, z_s, None, train=False)
             z_rec = self.enc.forward(V.enc2, out2, None, train=False)
-            n = ops.mse_fwd_bwd(z_rec, z_s, nv * ns, V.lpart, None)
-            ops.loss_finalize(V.lpart, n, 1.0, V.out, 3)
+            ops.mse_fwd_bwd(z_rec, z_s, nv * ns, V.lpart, None, fin=(1.0, V.out, 3, -1, V.ticket))
             self.disc.forward_backward(V.disc, V.sl_disc, z, V.out[0:1], train=False)
             V.metrics.launch(z)      # Shapiro-Wilk W per style, Spearman rho per pair (trainer.py:286-292)
             return z

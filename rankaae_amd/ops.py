@@ -139,26 +139,37 @@ def group_mean(x, groups, per, L, out):
     check(_lib.load().raae_group_mean(_ptr(x), groups, per, L, _ptr(out), _stream()), "raae_group_mean")
 
 
-def recon_loss_fwd_bwd(spec_in, spec_out, B, L, scale, partial, dout):
+def _fin(fin):
+    """``fin = (scale, out, slot, acc_slot, ticket)``: the loss is finished inside the kernel (``raae_loss_fin_t``);
+    None: the partials are left for ``loss_finalize``."""
+    if fin is None:
+        return None
+    scale, out, slot, acc_slot, ticket = fin
+    f = _lib.LossFinT()
+    f.scale, f.out, f.slot, f.acc_slot, f.ticket = float(scale), out.data_ptr(), slot, acc_slot, ticket.data_ptr()
+    return C.byref(f)
+
+
+def recon_loss_fwd_bwd(spec_in, spec_out, B, L, scale, partial, dout, fin=None):
     n = C.c_int(0)
     check(_lib.load().raae_recon_loss_fwd_bwd(_ptr(spec_in), _ptr(spec_out), B, L, 1 if scale else 0,
-                                              _ptr(partial, torch.float64), C.byref(n), _ptr(dout), _stream()),
+                                              _ptr(partial, torch.float64), C.byref(n), _ptr(dout), _fin(fin), _stream()),
           "raae_recon_loss_fwd_bwd")
     return n.value
 
 
-def smooth_loss_fwd_bwd(x, B, L, taps, partial, dx):
+def smooth_loss_fwd_bwd(x, B, L, taps, partial, dx, fin=None):
     n = C.c_int(0)
     arr = (C.c_float * len(taps))(*[float(t) for t in taps])
     check(_lib.load().raae_smooth_loss_fwd_bwd(_ptr(x), B, L, arr, len(taps), _ptr(partial, torch.float64),
-                                               C.byref(n), _ptr(dx), _stream()), "raae_smooth_loss_fwd_bwd")
+                                               C.byref(n), _ptr(dx), _fin(fin), _stream()), "raae_smooth_loss_fwd_bwd")
     return n.value
 
 
-def mse_fwd_bwd(a, b, n_el, partial, da):
+def mse_fwd_bwd(a, b, n_el, partial, da, fin=None):
     n = C.c_int(0)
     check(_lib.load().raae_mse_fwd_bwd(_ptr(a), _ptr(b), n_el, _ptr(partial, torch.float64), C.byref(n), _ptr(da),
-                                       _stream()), "raae_mse_fwd_bwd")
+                                       _fin(fin), _stream()), "raae_mse_fwd_bwd")
     return n.value
 
 

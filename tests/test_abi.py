@@ -31,7 +31,7 @@ def test_library_loads_and_exports_every_symbol():
     assert _lib.load().raae_abi_version() == _lib.ABI_VERSION
     assert _lib.load().raae_source_digest().decode() == _lib.source_digest(), "stale build"
     # host-side validation rejects bad shapes without touching a GPU
-    assert _lib.load().raae_mse_fwd_bwd(None, None, 0, None, None, None, None) == -1
+    assert _lib.load().raae_mse_fwd_bwd(None, None, 0, None, None, None, None, None) == -1
     assert b"invalid argument" in _lib.load().raae_error_string(-1)
 
 

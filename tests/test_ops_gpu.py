@@ -647,3 +647,29 @@ def test_disc_fused_matches_autograd(n_real, n_fake, ns, drop):
     for q, r, name in zip(params, ref, ["dw1", "db1", "ds1", "dw2", "db2", "ds2", "dw3", "db3"]):
         got = slabs[:nsl, offs[id(q)]:offs[id(q)] + q.numel()].sum(0).view(r.shape)
         close(got, r, 2e-4, 1e-7 + 2e-4 * float(r.abs().max()), name)
+
+
+def test_loss_kernels_finish_in_kernel():
+    """``fin=...``: the last workgroup to arrive sums the partials inside the loss kernel; the value (and the
+    accumulating slot) equal what the separate raae_loss_finalize launch gives, bit for bit, call after call."""
+    from oracle.ref_model import gaussian_taps
+    g = torch.Generator().manual_seed(3)
+    B, L = 256, 256
+    x, y = dev(torch.rand(B, L, generator=g) + 0.2), dev(torch.rand(B, L, generator=g) + 0.2)
+    part = torch.zeros(_lib.RAAE_MAX_PARTS, dtype=torch.float64, device=DEV)
+    ticket = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ref, got = torch.zeros(8, device=DEV), torch.zeros(8, device=DEV)
+    taps = gaussian_taps(17, 3.0).tolist()
+    for rep in range(3):
+        n = ops.recon_loss_fwd_bwd(x, y, B, L, True, part, None)
+        ops.loss_finalize(part, n, 1.0, ref, 2)
+        ops.recon_loss_fwd_bwd(x, y, B, L, True, part, None, fin=(1.0, got, 2, -1, ticket))
+        n = ops.smooth_loss_fwd_bwd(y, B, L, taps, part, None)
+        ops.loss_finalize(part, n, 1.0, ref, 4)
+        ops.smooth_loss_fwd_bwd(y, B, L, taps, part, None, fin=(1.0, got, 4, -1, ticket))
+        n = ops.mse_fwd_bwd(x, y, B * L, part, None)
+        ops.loss_finalize(part, n, 1.0, ref, 3, 5)
+        ops.mse_fwd_bwd(x, y, B * L, part, None, fin=(1.0, got, 3, 5, ticket))
+        assert torch.equal(ref, got), (rep, ref, got)
+        assert int(ticket) == 0
+    assert float(got[5]) > 2.5 * float(got[3]) > 0           # three accumulations
