@@ -455,13 +455,16 @@ class StepEngine:
             # GPU: the cuts and event hops of the segmented path cost 45 us per phase.
             self.graph_ar = None
             if self.cfg.get("in_graph_allreduce", True) and dist.get_backend(self.pg) == "nccl":
-                from .rccl import GraphAllReduce
+                from .rccl import GraphAllReduce, agree
+                ar = None
                 try:
                     ar = GraphAllReduce(dist.get_rank(self.pg), dist.get_world_size(self.pg), device, self.pg)
-                    if ar.self_test():
-                        self.graph_ar = ar
                 except Exception:                                            # noqa: BLE001 -- fall back
-                    self.graph_ar = None
+                    ar = None
+                # EVERY rank takes part in the agreement, also one whose communicator could not be created: a rank
+                # that skipped it would leave the others waiting in the collective
+                ok = ar.self_test() if ar is not None else agree(False, device, self.pg)
+                self.graph_ar = ar if ok else None
         from .nets_conv import CompactNet   # local import: conv emitters live in their own module
         if cfg["ae_form"] == "FC":
             self.enc, self.dec = FCNet(encoder, "enc", self), FCNet(decoder, "dec", self)

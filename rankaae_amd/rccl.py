@@ -34,6 +34,16 @@ def _load():
     return lib
 
 
+def agree(ok, device, group=None):
+    """True only when ``ok`` on EVERY rank of ``group`` (one MIN all-reduce on the torch process group; every rank
+    must call it exactly once per decision)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        flag = torch.tensor([1 if ok else 0], device=device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        ok = bool(int(flag) == 1)
+    return bool(ok)
+
+
 class GraphAllReduce:
     """Mean all-reduce of fp32 device buffers on the CURRENT torch stream; legal under hipGraph capture."""
 
@@ -88,11 +98,7 @@ class GraphAllReduce:
                 ok = ok and bool(torch.allclose(y, torch.full_like(y, want)))
         except Exception:                                     # noqa: BLE001 -- any failure means "fall back"
             ok = False
-        if self.world > 1:
-            flag = torch.tensor([1 if ok else 0], device=self.device, dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-            ok = bool(int(flag) == 1)
-        return ok
+        return agree(ok, self.device, self.group)
 
     def close(self):
         if self.comm:
