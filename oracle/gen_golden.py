@@ -80,6 +80,13 @@ CASES = {
                                       use_flex_spec_target=False, epoch_stop_smooth=0), 3, 7),
     "fc_512_aux12": (350, 512, dict(ae_form="FC", batch_size=64, max_epoch=1, dim_in=512, dim_out=512,
                                     n_aux=12, nstyle=13), 1, 99),
+    # lr_base = 0: Adam/AdamW leave every weight where it is, so the trajectory is NOT chaotic (SURVEY finding 8
+    # is about the updates) while everything else still runs -- the five forward/backward phases of every step incl.
+    # the ragged last batch, the random tape, the BatchNorm running statistics of 6 + 4 train-mode forwards per
+    # step, and the per-epoch validation pass in eval mode on those running statistics.  A FREE-RUNNING
+    # implementation can be held to these values over two whole epochs (tests/test_engine_gpu.py::test_p4_*).
+    "fc_frozen": (700, 256, dict(ae_form="FC", batch_size=64, max_epoch=2, lr_base=0.0), 5, 4321),
+    "compact_frozen": (700, 256, dict(ae_form="compact", batch_size=64, max_epoch=2, lr_base=0.0), 5, 4321),
 }
 
 
@@ -155,6 +162,9 @@ def run_case(name, case=None, write=True):
     for fn, orig in originals.items():
         setattr(T, fn, orig)
     T.ReduceLROnPlateau = orig_sched
+    bn_buffers = {nm: {k: v.double().numpy().tolist() for k, v in mod.state_dict().items()
+                       if k.endswith("running_mean") or k.endswith("running_var")}
+                  for nm, mod in (("Encoder", trainer.encoder), ("Decoder", trainer.decoder))}
 
     n_train_rows = int(n_rows * 0.7)
     steps_per_epoch = -(-n_train_rows // cfg["batch_size"])
@@ -168,6 +178,8 @@ def run_case(name, case=None, write=True):
         "loss_calls": rec, "epoch_metrics": epoch_metrics, "final_metrics": [float(x) for x in metrics],
         "losses_csv": lines, "init_checksum": init, "final_checksum": final, "val_styles_first8": styles,
     }
+    if name.endswith("_frozen"):
+        fixture["final_bn_buffers"] = bn_buffers
     if not write:
         return fixture
     out = os.path.join(REPO, "tests", "golden", f"ref_{name}.json")

@@ -164,6 +164,7 @@ class FCNet:
         self.in_dim, self.out_dim = self.layers[0].K, self.layers[-1].N
         self.final_relu = kind == "dec" and isinstance(module.main[-1], nn.ReLU)
         self.bn_modules = [l.bn for l in self.layers if l.bn is not None]
+        self.pairable = True       # forward_steps yields at every layer, the first time before anything is written
 
     def alloc(self, b):
         dev = self.eng.device
@@ -667,7 +668,7 @@ class StepEngine:
             P.max_slab[name] = int(notes_host.max())      # host-side hint for the Adam kernel's lane split
         self.join_side_streams()
         if self.phase_hook is not None:      # debugging / parity tests: gradients before the update
-            self.phase_hook(name, P)
+            self._host_hook(self.phase_hook, name, P)
         lo, n = o.lo, o.hi - o.lo
         if self.world_size > 1:
             # flat gradient -> RCCL mean over ranks -> Adam on the averaged single slab
@@ -679,7 +680,21 @@ class StepEngine:
             ops.adam_step(self.arena.P[lo:], o.m, o.v, self.G[0, lo:], self.arena.n, P.seg[name][lo // 64:], n,
                           o.hyper, self.steps_dev[o.index:], self.decoupled, P.max_slab[name])
         if self.post_phase_hook is not None:  # parity tests: teacher forcing at phase granularity
-            self.post_phase_hook(name, P)
+            self._host_hook(self.post_phase_hook, name, P)
+
+    def _host_hook(self, fn, name, P):
+        """A host callback between two launches (parity tests).  Eager emission: call it now.  Under capture: the
+        graph is cut here -- the segment so far ends, the callback becomes an item of the replay list, a new
+        segment begins (all branches were joined just before, so the cut is legal)."""
+        if self._capture is None:
+            fn(name, P)
+            return
+        g = self._capture["cur"]
+        g.end()
+        self._capture["items"] += [g, lambda: fn(name, P)]
+        g = ops.Graph()
+        g.begin()
+        self._capture["cur"] = g
 
     def _all_reduce(self, buf):
         """Mean over ranks on a dedicated communication stream.  RCCL's work events must never be recorded
@@ -741,7 +756,11 @@ class StepEngine:
         # per pair of block kernels) -- phase A updates neither the decoder nor, before that forward's last
         # kernel, `styles`, so the results are bit for bit those of running it here
         # (tests/test_engine_gpu.py::test_paired_forwards_change_nothing).  Branched graph: beside phase A.
-        pair = (not self._branch) and hasattr(enc, "forward_steps") and bool(c.get("pair_unused_forwards", True))
+        # Only legal when the encoder's forward hands control back (one yield per launch) before it overwrites
+        # `styles`, so that the deferred decoder forward's first launch -- the only one that reads `styles` -- is
+        # issued first: true for the dense networks and for fused residual blocks, not for the per-layer conv path.
+        pair = ((not self._branch) and bool(c.get("pair_unused_forwards", True)) and
+                getattr(enc, "pairable", False) and getattr(dec, "pairable", False))
         if not pair:
             with self.aux_branch():
                 dec.forward(D, styles, P.m_dec[0])
@@ -839,6 +858,8 @@ class StepEngine:
             for item in P.graphs[key]:
                 if isinstance(item, ops.Graph):
                     item.launch()
+                elif callable(item):
+                    item()
                 else:
                     self._all_reduce(item)
             self._count_bn_step(smooth)

@@ -77,6 +77,9 @@ class CompactNet:
             self.act = OUT_RELU if isinstance(act, nn.ReLU) else OUT_SOFTPLUS
             self.in_dim, self.out_dim = self.blocks[0].Cin, L
             self.bn_modules = [b for blk in self.blocks for b in blk.bns] + [self.bn_f]
+        # forward_steps yields only at fused-block launches: with a per-layer first block it would run through to
+        # its output before the paired chain has issued anything (StepEngine.emit_step, `pair`)
+        self.pairable = self.fused and self.blocks[0].Cin <= 8 and self.blocks[0].Cout <= 8
 
     # ------------------------------------------------------------------ workspaces
     def alloc(self, b):

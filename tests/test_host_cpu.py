@@ -205,3 +205,70 @@ def test_trial_assignment_round_robin():
     assert assign_trials(5, 2) == [[0, 2, 4], [1, 3]]
     assert assign_trials(3, 8)[:3] == [[0], [1], [2]] and all(not j for j in assign_trials(3, 8)[3:])
     assert sorted(k for part in assign_trials(32, 8) for k in part) == list(range(32))
+
+
+@pytest.mark.parametrize("case", ["fc_frozen", "compact_frozen"])
+def test_exported_modules_forward_is_the_reference_forward(case):
+    """``final.pt`` consumers (the reference's report tool, ``sc/report/generate_report.py:272-275``) call the
+    plain-PyTorch ``forward`` of ``rankaae_amd.model``'s containers.  Pin that arithmetic (reference
+    ``sc/clustering/model.py:330-378, 264-295, 430-474, 518-570, 631-663``):
+      * with the oracle's ``state_dict`` loaded, train-mode (same dropout draws, BatchNorm batch statistics and
+        running-statistics updates) and eval-mode forwards of encoder, decoder and discriminator equal
+        ``oracle.ref_model``'s to 1e-6;
+      * through the oracle's trained state of a ``*_frozen`` fixture (lr_base = 0: the weights stay at their
+        initial values, the BatchNorm running statistics of two epochs are not chaotic -- see oracle/gen_golden.py)
+        the eval-mode encoder reproduces the REFERENCE's ``val_styles_first8`` to 1e-5."""
+    from oracle import ref_train
+    with open(os.path.join(GOLDEN, f"ref_{case}.json")) as f:
+        g = json.load(f)
+    c = g["config"]
+    spec, aux, _ = make_spectra(g["n_rows"], g["n_points"], c["n_aux"], seed=g["data_seed"])
+    torch.set_num_threads(1)
+    torch.manual_seed(g["model_seed"])
+    tr = ref_train.OracleTrainer(spec, aux, c)
+    tr.train()                                                  # 2 epochs; running statistics move, weights do not
+    cls = pm.AE_CLS_DICT[c["ae_form"]]
+    enc = cls["encoder"](nstyle=c["nstyle"], dropout_rate=c["dropout_rate"], dim_in=c["dim_in"], n_layers=c["n_layers"])
+    dec = cls["decoder"](nstyle=c["nstyle"], dropout_rate=c["dropout_rate"], last_layer_activation=c["decoder_activation"],
+                         dim_out=c["dim_out"], n_layers=c["n_layers"])
+    dis = pm.DiscriminatorFC(nstyle=c["nstyle"], dropout_rate=c["dis_dropout_rate"], noise=c["dis_noise"],
+                             layers=c["FC_discriminator_layers"])
+    for mine, theirs in ((enc, tr.encoder), (dec, tr.decoder), (dis, tr.discriminator)):
+        mine.load_state_dict(theirs.state_dict(), strict=True)
+    n_train = int(g["n_rows"] * 0.7)
+    x = torch.tensor(spec[n_train:n_train + 48], dtype=torch.float32)
+    z_in = torch.randn(48, c["nstyle"])
+    for train in (True, False):
+        for m in (enc, dec, dis, tr.encoder, tr.decoder, tr.discriminator):
+            m.train(train)
+        outs = []
+        for e_, d_, s_ in ((enc, dec, dis), (tr.encoder, tr.decoder, tr.discriminator)):
+            torch.manual_seed(99)                               # same dropout / input-noise draws on both sides
+            with torch.no_grad():
+                z = e_(x)
+                outs.append((z, d_(z), d_(z_in), s_(z, 0.3)))
+        for a, b in zip(*outs):
+            assert a.shape == b.shape and torch.allclose(a, b, rtol=1e-6, atol=1e-6), (case, train)
+        if train:                                               # the train-mode forwards moved the running statistics alike
+            for mine, theirs in ((enc, tr.encoder), (dec, tr.decoder)):
+                for (k, v), (_, w) in zip(mine.state_dict().items(), theirs.state_dict().items()):
+                    assert torch.allclose(v.double(), w.double(), rtol=1e-6, atol=1e-7), (case, k)
+    # the gradient-reversal layer of the container (model.py:8-22)
+    zz = torch.randn(5, c["nstyle"], requires_grad=True)
+    dis.eval()
+    dis(zz, 0.25).sum().backward()
+    zz2 = zz.detach().clone().requires_grad_(True)
+    tr.discriminator.eval()
+    tr.discriminator(zz2, 0.25).sum().backward()
+    assert torch.allclose(zz.grad, zz2.grad, rtol=1e-6, atol=1e-7)
+    # ... and against the reference itself: reload the post-training state (the train-mode forwards above moved it)
+    torch.manual_seed(g["model_seed"])
+    tr2 = ref_train.OracleTrainer(spec, aux, c)
+    tr2.train()
+    enc.load_state_dict(tr2.encoder.state_dict())
+    enc.eval()
+    with torch.no_grad():
+        st = enc(torch.tensor(spec[n_train:n_train + 8], dtype=torch.float32)).double().numpy()
+    assert np.allclose(st, g["val_styles_first8"], rtol=1e-5, atol=1e-5), np.abs(st - np.array(g["val_styles_first8"])).max()
+    for key, want in g["final_bn_buffers"]["Encoder"].items():
+        assert np.allclose(enc.state_dict()[key].double().numpy(), want, rtol=1e-5, atol=1e-6), key
