@@ -3,6 +3,7 @@
 
     python bench.py --gpus N --steps K --warmup W [--ae-form compact|FC] [--batch 256]
 
+With ``--gpus N`` and no launcher (WORLD_SIZE unset) it starts its N rank processes itself.
 One "step" = the reference's five-phase update (adversarial, rank, reconstruction,
 mutual-information, smoothness: 6 encoder + 4 decoder forwards, 5 backwards, 5 AdamW
 updates; ``sc/clustering/trainer.py:103-204``) on one batch of 256 synthetic 256-point
@@ -114,16 +115,88 @@ def epoch_inclusive(cfg, spec, aux, epochs=8):
 
 
 def pmc_traffic(kernel, ae_form, b):
-    """HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC summary (FETCH_SIZE and
-    WRITE_SIZE collected in separate passes of this same command, profiles/r1_pmc_traffic_*.json);
-    None when there is no summary for this workload.  Counters cannot be read from inside the process."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                        f"r1_pmc_traffic_{ae_form.lower()}_b{b}.json")
+    """HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC summary of THIS round's build (FETCH_SIZE
+    and WRITE_SIZE collected in separate ``--pmc`` passes of this same command and summarised by tools/pmc_summary.py
+    into profiles/r2_pmc_traffic_*.json); None when there is no summary for this workload or kernel.  Hardware
+    counters cannot be read from inside the process."""
+    path = os.path.join(REPO, "profiles", f"r2_pmc_traffic_{ae_form.lower()}_b{b}.json")
     if not os.path.exists(path):
         return None
     with open(path) as f:
-        k = json.load(f)["kernels"].get(kernel)
-    return k["hbm_bytes_raw"] if k else None
+        kernels = json.load(f)["kernels"]
+    for name, k in kernels.items():
+        if name.split("<")[0] == kernel.split("<")[0]:
+            return k["hbm_bytes_raw"]
+    return None
+
+
+def cpu_calibration(ae_form):
+    """port / reference steps-per-second ratio measured in the build container (oracle/calibrate.py), so that the
+    port's number on this box can be read as the reference's."""
+    path = os.path.join(REPO, "profiles", "cpu_calibration.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        c = json.load(f)
+    return c.get(ae_form, {}).get("port_over_reference")
+
+
+def spawn_ranks(n):
+    """``python bench.py --gpus N`` without a launcher: start the N rank processes ourselves (one
+    ``torch.distributed.run`` child, rendezvous on 127.0.0.1) BEFORE anything in this process touches the GPU,
+    pass their output through and exit with their code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def configs2_line(args, cfg0, dev):
+    """BASELINE configs[2] beside the headline: 100 k synthetic spectra, batch 4096 -- the regime where the conv
+    kernels stop being launch-bound.  Same engine, same step; returns steps/s and the top kernels' roofline."""
+    from rankaae_amd.engine import StepEngine
+    from rankaae_amd.synthetic import make_spectra
+    from rankaae_amd.dataloader import split_counts
+    cfg = dict(cfg0, batch_size=4096)
+    rows, b = 100000, 4096
+    spec, aux, _ = make_spectra(rows, cfg["dim_in"], cfg["n_aux"], seed=0)
+    n_train = split_counts(rows)[0]
+    enc, dec, dis = build_models(cfg, 1234)
+    eng = StepEngine(enc, dec, dis, cfg, dev, rng_mode="philox", seed=1234, use_graph=not args.no_graph)
+    eng.set_data(spec[:n_train], aux[:n_train])
+    full = n_train // b
+    gen = torch.Generator().manual_seed(7)
+    i = 0
+
+    def one_step():
+        nonlocal i
+        if i % full == 0:
+            eng.set_epoch(torch.randperm(n_train, generator=gen), 0.7172)
+        eng.step(b, smooth=True)
+        i += 1
+    for _ in range(4):
+        one_step()
+    torch.cuda.synchronize()
+    steps = 40
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"workload": f"BASELINE configs[2]: {rows}x{cfg['dim_in']} synthetic spectra (train split {n_train}), batch {b}, "
+                       f"ae_form={cfg['ae_form']}", "value": round(steps / dt, 2), "unit": "steps/s",
+           "spectra_per_s": round(steps * b / dt), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps}
+    if not args.no_roofline:
+        out["roofline"] = eng.roofline_probe(b, HBM_PEAK_GBS, reps=2)
+        for r in out["roofline"]["top_kernels"]:
+            r["traffic"] = pmc_traffic(r["kernel"], cfg["ae_form"], b)
+        out["roofline"]["traffic"] = out["roofline"]["top_kernels"][0]["traffic"]
+    return out
 
 
 def main():
@@ -138,20 +211,26 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-oracle timing (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-epoch", action="store_true", help="skip the epoch-inclusive (validation + metrics) timing")
+    ap.add_argument("--no-configs2", action="store_true", help="skip the batch-4096 / 100k-row sub-run (configs[2])")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
                     help="override an engine tuning key (side_streams, overlap_unused_forwards, fused_blocks)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)              # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # rehearsal on a one-GPU box: RANKAAE_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo (RCCL refuses
     # two ranks on one device); it exercises sharding, graph segmentation and the collectives, not the speed
     rehearsal = os.environ.get("RANKAAE_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} GPU(s) are visible "
+                         "(RANKAAE_BENCH_REHEARSAL=1 rehearses the multi-rank path on one GPU over gloo)")
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     if world > 1:
@@ -222,27 +301,47 @@ def main():
 
     if rank == 0:
         value = world * args.steps / dt
+        named = "BASELINE configs[1]" if (b, args.rows) == (256, 7000) else \
+            ("BASELINE configs[2]" if (b, args.rows) == (4096, 100000) else "custom workload")
+        rccl_ranks = 1
+        if world > 1:
+            rccl_ranks = eng.graph_ar.world if eng.graph_ar is not None else dist.get_world_size()
         line = {
-            "metric": "training steps/sec (batch=256, 256-pt spectra)", "value": round(value, 2),
+            "metric": f"training steps/sec (batch={b}, {cfg['dim_in']}-pt spectra)", "value": round(value, 2),
             "unit": f"steps/s (five-phase steps on {b}-row batches, summed over ranks)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: {rows}x{cfg['dim_in']} synthetic spectra ({args.rows} per GPU; train split "
+            "config": {"workload": f"{named}: {rows}x{cfg['dim_in']} synthetic spectra ({args.rows} per GPU; train split "
                                    f"{n_train}), batch {b}/GPU, ae_form={cfg['ae_form']}, nstyle={cfg['nstyle']}, "
                                    f"n_aux={cfg['n_aux']}, AdamW, 5 phases incl. smoothness",
                        "global_batch": b * world, "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
-                       "rng": "philox tape (device)"},
+                       "rng": "philox tape (device)", "rccl_ranks": rccl_ranks,
+                       "collective": (None if world == 1 else ("in-graph ncclAllReduce" if eng.graph_ar is not None
+                                                               else f"torch.distributed {dist.get_backend()} between graph segments"))},
             "losses_finite": finite, "last_losses": {k: round(v, 6) for k, v in losses.items()},
         }
         # the extras run on ONE GPU only: with several ranks the probe's extra training steps would enter
         # collectives the other ranks never join, and the contract asks for the CPU baseline at N = 1
         if not args.no_roofline and world == 1:
             line["roofline"] = eng.roofline_probe(b, HBM_PEAK_GBS)
-            line["roofline"]["traffic"] = pmc_traffic(line["roofline"]["kernel"], cfg["ae_form"], b)
+            for r in line["roofline"]["top_kernels"]:
+                r["traffic"] = pmc_traffic(r["kernel"], cfg["ae_form"], b)
+            line["roofline"]["traffic"] = line["roofline"]["top_kernels"][0]["traffic"]
+            if b < 1024:
+                line["roofline"]["note"] = ("this batch is launch/latency bound (SURVEY 8d): every kernel moves <= 2.5 MB; "
+                                            "the HBM-bound regime is the configs2 sub-run below")
         if not args.no_epoch and world == 1:
             line["epoch_inclusive"] = epoch_inclusive(cfg, spec, aux)
+        if not args.no_configs2 and world == 1 and (b, args.rows) == (256, 7000):
+            del eng
+            torch.cuda.empty_cache()
+            line["configs2"] = configs2_line(args, cfg, dev)
         if args.cpu_budget > 0 and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg, spec, aux, args.cpu_budget)
+            ratio = cpu_calibration(cfg["ae_form"])
+            if ratio:
+                line["cpu_baseline"]["port_over_reference"] = ratio
+                line["cpu_baseline"]["reference_equivalent"] = round(line["cpu_baseline"]["value"] / ratio, 3)
             line["speedup_vs_cpu_baseline"] = round(value / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -301,3 +301,54 @@ class OracleTrainer:
                 callback(epoch, metrics)
         torch.autograd.set_detect_anomaly(prev_anomaly)
         return metrics
+
+
+# ----------------------------------------------------------------------------- derived parity bounds
+GRAD_NOISE = 1e-5     # |g|_inf-relative distance of two correct fp32 evaluations of one gradient (DESIGN.md section 7:
+#                       the reference's own fp32 gradient is 4.7e-5 from float64 arithmetic behind the first BatchNorm)
+
+
+def first_step(cfg, model_seed, spec, aux, mode=0, alpha_=0.0):
+    """The oracle's FIRST training step from ``model_seed`` under a perturbation of rounding-error size:
+      mode  0        none
+      mode +1 / -1   every input spectrum value one float32 ulp up / down
+      mode  2..9     a random up/down one-ulp pattern over the inputs (seeded with ``mode``)
+      mode >= 10     every parameter gradient g of every phase becomes g + GRAD_NOISE * |g|_inf * N(0, 1) before the
+                     optimizer step (private generator seeded with ``mode``; the global generator is not touched) --
+                     what a second fp32 implementation with another summation order hands to Adam."""
+    s32 = np.asarray(spec, dtype=np.float32)
+    up, down = np.nextafter(s32, np.float32(np.inf)), np.nextafter(s32, np.float32(-np.inf))
+    if mode == 1:
+        s32 = up
+    elif mode == -1:
+        s32 = down
+    elif 2 <= mode < 10:
+        s32 = np.where(np.random.default_rng(mode).integers(0, 2, s32.shape).astype(bool), up, down)
+    torch.manual_seed(model_seed)
+    tr = OracleTrainer(s32.astype(np.float64), aux, cfg)
+    for m in (tr.encoder, tr.decoder, tr.discriminator):
+        m.train()
+    if mode >= 10:
+        gen = torch.Generator().manual_seed(mode)
+
+        def noisy(name):
+            for grp in tr.optimizers[name].param_groups:
+                for p in grp["params"]:
+                    if p.grad is not None:
+                        p.grad.add_(torch.randn(p.grad.shape, generator=gen) * (GRAD_NOISE * float(p.grad.abs().max())))
+        tr.phase_hook = noisy
+    rows = epoch_permutation(len(tr.train_spec)).numpy()[:cfg["batch_size"]]
+    epoch = 0 if 0 < cfg.get("epoch_stop_smooth", 500) else 10 ** 9
+    return tr.train_step(torch.tensor(tr.train_spec[rows], dtype=torch.float32),
+                         torch.tensor(tr.train_aux[rows], dtype=torch.float32), alpha_, epoch)
+
+
+def derived_bounds(cfg, model_seed, spec, aux, keys, modes=(1, -1, 2, 3, 11, 12, 13, 14), alpha_=0.0):
+    """``(oracle losses, {key: bound})`` for a first-step comparison.  The losses of the later phases follow Adam's
+    first, sign-like updates (step = lr * g / (|g| + eps): an entry whose gradient is rounding noise moves by +-lr)
+    and amplify rounding noise (SURVEY finding 8); how much is MEASURED, not guessed: the bound is 3x the largest
+    move of the oracle's own loss over eight perturbations of rounding-error size (``first_step``), plus a 1e-4
+    relative floor."""
+    base = first_step(cfg, model_seed, spec, aux, 0, alpha_)
+    pert = [first_step(cfg, model_seed, spec, aux, m, alpha_) for m in modes]
+    return base, {k: 3.0 * max(abs(p[k] - base[k]) for p in pert) + 1e-4 * abs(base[k]) + 1e-7 for k in keys}

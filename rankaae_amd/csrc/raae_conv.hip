@@ -743,7 +743,7 @@ static int prep_block_fwd_a(const raae_block_fwd_a_t* in, raae_block_fwd_a_t& a,
     RAAE_CHECK_ARG(in->cv1.Cin == in->Cin && in->cv1.Cout == in->Cout && in->cv1.Lin == in->Lin && in->cv1.Lout == in->L1);
     RAAE_CHECK_ARG(!in->has_short || (in->cvs.Lin == in->Lin && in->cvs.Lout == in->Lout && in->cvs.pad == 0));
     a = *in;
-    a.halo = a.cv1.transposed ? 0 : a.cv1.pad;
+    a.halo = tile_halo(a.cv1);
     const long wfl = conv_nw(&a.cv1) + (a.has_short ? conv_nw(&a.cvs) : 0) + 2L * a.E * (a.Lin > a.Lout ? a.Lin : a.Lout);
     const long per = (long)a.Cin * (a.Lin + 2 * a.halo) + (long)a.Cin * a.E;
     RAAE_CHECK_ARG(wfl <= 4096 && per <= kTileBudget);
@@ -778,7 +778,7 @@ static int prep_block_fwd_b(const raae_block_fwd_b_t* in, raae_block_fwd_b_t& a,
     RAAE_CHECK_ARG(in->has_excit ? (conv_ok(&in->cve) && in->E3 && in->cve.K == 1) : in->Cin == in->Cout);
     RAAE_CHECK_ARG(in->T2 && in->Y && in->pY && in->cv2.Lin == in->L1 && in->cv2.Lout == in->Lout);
     a = *in;
-    a.halo2 = a.cv2.transposed ? 0 : a.cv2.pad;
+    a.halo2 = tile_halo(a.cv2);
     RAAE_CHECK_ARG(a.cv2.transposed || !a.cv2.pad_replicate);
     const long per = (long)a.Cout * (a.L1 + 2 * a.halo2) + (a.has_excit ? (long)a.Cin * a.Lout : 0);
     RAAE_CHECK_ARG(per <= kTileBudget);
@@ -896,7 +896,10 @@ static int prep_block_bwd_b(const raae_block_bwd_b_t* in, raae_block_bwd_b_t& a,
     RAAE_CHECK_ARG(in->T2 && in->Ex && in->dT2 && in->dSh && in->dEx && in->dBn2 && in->pdBn2 && in->dslope2 && in->dslope_e);
     RAAE_CHECK_ARG(!in->has_short || (in->Sh && in->ss && in->dslope_s));
     a = *in;
-    const long per = (long)a.Cout * a.Lout * (a.has_excit ? 2 : 1);
+    kind = blk_kind_b(a.Cin, a.Cout, a.L1, a.Lout, a.cv2, a.has_short, a.has_excit, a.cve);
+    // strip instances (block_bwd_b_body: kStripB) keep an 8-float zero margin on both sides of every dT2 row
+    const int gm = (kind >= 0 && strip_conv_ok(kBlk[kind].cv2)) ? kStripMargin : 0;
+    const long per = (long)a.Cout * (a.Lout + 2 * gm) + (a.has_excit ? (long)a.Cout * a.Lout : 0);
     RAAE_CHECK_ARG(per <= kTileBudget);
     long widest = (long)a.Cout * a.Lout;
     if ((long)a.Cout * a.L1 > widest) widest = (long)a.Cout * a.L1;
@@ -905,7 +908,6 @@ static int prep_block_bwd_b(const raae_block_bwd_b_t* in, raae_block_bwd_b_t& a,
     a.sh_l1 = lg2(a.L1); a.sh_lout = lg2(a.Lout);
     grid = a.ngroups < 512 ? a.ngroups : 512;
     lds = sizeof(float) * ((size_t)a.S * per + conv_nw(&a.cv2) + (a.has_excit ? conv_nw(&a.cve) : 0));
-    kind = blk_kind_b(a.Cin, a.Cout, a.L1, a.Lout, a.cv2, a.has_short, a.has_excit, a.cve);
     return 0;
 }
 
@@ -929,8 +931,11 @@ extern "C" int raae_block_bwd_a(const raae_block_bwd_a_t* in, int* nparts, void*
     RAAE_CHECK_ARG(in->E1 && in->dSh && in->dT1 && in->dE2 && in->dE1 && in->dslope1 && in->dslope_e1 && in->se1);
     RAAE_CHECK_ARG(!in->pdR || (in->dR && in->in.has_bn));
     raae_block_bwd_a_t a = *in;
+    const int kind = blk_kind_a(a.Cin, a.Cout, a.Lin, a.L1, a.Lout, a.E, a.cv1, a.has_short, a.cvs, a.has_excit, true);
+    // strip instances (block_bwd_a_kernel: kStripA) keep an 8-float zero margin on both sides of every dT1 row
+    const int gm = (kind >= 0 && strip_conv_ok(kBlk[kind].cv1) && !kBlk[kind].has_short) ? kStripMargin : 0;
     const long wfl = conv_nw(&a.cv1) + (a.has_short ? conv_nw(&a.cvs) : 0) + (long)a.E * a.Lin + (long)a.Lout * a.E;
-    const long per = (long)a.Cout * a.L1 + (long)a.Cout * a.Lout + (long)a.Cin * a.Lout + (long)a.Cin * a.E;
+    const long per = (long)a.Cout * (a.L1 + 2 * gm) + (long)a.Cout * a.Lout + (long)a.Cin * a.Lout + (long)a.Cin * a.E;
     RAAE_CHECK_ARG(wfl <= 4096 && per <= kTileBudget);
     long widest = (long)a.Cin * a.Lin;
     if ((long)a.Cout * a.L1 > widest) widest = (long)a.Cout * a.L1;
@@ -942,7 +947,6 @@ extern "C" int raae_block_bwd_a(const raae_block_bwd_a_t* in, int* nparts, void*
     const int grid = a.ngroups < 512 ? a.ngroups : 512;
     if (nparts) *nparts = grid;
     const size_t lds = sizeof(float) * ((size_t)a.S * per + wfl);
-    const int kind = blk_kind_a(a.Cin, a.Cout, a.Lin, a.L1, a.Lout, a.E, a.cv1, a.has_short, a.cvs, a.has_excit, true);
     RAAE_LAUNCH_KIND(block_bwd_a_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a)
     RAAE_LAUNCH_RET();
 }

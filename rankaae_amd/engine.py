@@ -209,8 +209,7 @@ class FCNet:
         try:
             _, args, nbytes = next(steps)
             while True:
-                _, args, nbytes = steps.send(self.eng.probe_launch("dense_fwd", nbytes,
-                                                                   lambda: ops.dense_fwd_struct(args)))
+                _, args, nbytes = steps.send(ops.dense_fwd_struct(args))
         except StopIteration as done:
             return done.value
 
@@ -491,7 +490,6 @@ class StepEngine:
         self.phase_hook = None
         self.post_phase_hook = None
         self._capture = None
-        self._probe = None
         n_side = int(self.cfg.get("side_streams", 3))
         self.side_streams = [torch.cuda.Stream(device=device) for _ in range(n_side)]
         self._side_i, self._side_used, self._events = 0, set(), []
@@ -612,6 +610,26 @@ class StepEngine:
         self._host_cursor = int(start)       # host mirror of the device row cursor (bounds check)
         self.alpha_dev.fill_(float(alpha))
         self.loss_out[LOSS_SLOTS["mi_accum"]] = 0.0
+
+    @_on_stream
+    def seek(self, start, stride=None):
+        """Move the device row cursor inside the current epoch: the next step of ``b`` rows reads
+        ``perm[start : start + b]`` and the following ones advance by ``stride`` (default: b)."""
+        self.cursor_start, self.cursor_stride = int(start), stride
+        self._cursor_primed = False
+        self._host_cursor = int(start)
+
+    def close(self):
+        """Release the private RCCL communicator (data-parallel runs)."""
+        if self.graph_ar is not None:
+            self.graph_ar.close()
+            self.graph_ar = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001 -- interpreter shutdown
+            pass
 
     # -- plan construction
     def plan(self, b):
@@ -866,90 +884,41 @@ class StepEngine:
         else:
             self.emit_step(P, smooth, record=False)
 
-    # -- roofline probe (bench.py): HIP-event timing of every launch of the step's dominant kernel
-    def probe_launch(self, kind, nbytes, fn):
-        """Run ``fn`` (one kernel launch); when a probe for ``kind`` is armed, bracket it with HIP
-        events recorded on the stream the kernel is launched on."""
-        pr = self._probe
-        if pr is None or pr["kind"] != kind:
-            return fn()
-        out = fn()                      # the launch that belongs to the step
-        # ... and PROBE_REPS identical launches, captured into a small hipGraph and replayed between two
-        # events on this stream: a single bracketed launch in eager mode measures the host's submission
-        # latency (tens of us), not the kernel.  The extra launches rewrite the same outputs.
-        g = ops.Graph()
-        g.begin()
-        for _ in range(PROBE_REPS):
-            fn()
-        g.end()
-        e0, e1 = ops.Event(), ops.Event()
-        e0.record()
-        g.launch()
-        e1.record()
-        pr["graphs"].append(g)
-        pr["events"].append((e0, e1, nbytes))
-        return out
-
+    # -- roofline probe (bench.py): HIP-event timing of every kernel family the step launches
     @_on_stream
-    def roofline_probe(self, b, peak_gbs, reps=5):
-        """Dominant kernel of this workload (by rocprofv3 share: phase A of the fused residual-block forward
-        for ``compact``, fused dense forward for ``FC``): algorithmic bytes per launch / average
-        HIP-event duration, over ``reps`` eager steps; plus the same for the largest Conv1d of the
-        model run alone at batch 4096, where the launch floor no longer hides the kernel."""
-        kind = "block_fwd_a" if self.cfg["ae_form"] == "compact" else "dense_fwd"
-        saved_graph, saved_hooks = self.use_graph, (self.phase_hook, self.post_phase_hook)
+    def roofline_probe(self, b, peak_gbs, reps=3, top=3):
+        """``reps`` eager steps with ``ops.PROBE`` armed: every launch of the step is followed by ten identical
+        launches replayed from a small hipGraph between two HIP events on the launching stream.  Returns the ``top``
+        kernel families by share of the summed kernel time, each with its algorithmic bytes per launch (ops.block_bytes
+        and friends: SURVEY 8d's per-sample figure x the batch), average launch duration and fraction of the HBM peak;
+        the first one is the step's dominant kernel."""
+        saved_graph = self.use_graph
         self.use_graph = False
         self.set_epoch(self.perm.clone(), float(self.alpha_dev))
-        self._probe = {"kind": kind, "events": [], "graphs": []}
-        for _ in range(reps):
-            self.step(b, smooth=True)
-        torch.cuda.synchronize()
-        ev = self._probe["events"]
-        self._probe = None
-        self.use_graph = saved_graph
-        t_us = [1e3 * a.elapsed_ms(z) / PROBE_REPS for a, z, _ in ev]
-        nbytes = [n for *_, n in ev]
-        avg_us, avg_bytes = float(np.mean(t_us)), float(np.mean(nbytes))
-        ach = avg_bytes / (avg_us * 1e-6) / 1e9
-        out = {"bound": "hbm", "kernel": {"block_fwd_a": "block_fwd_a_kernel", "block_wgrad": "wgrad_multi_kernel",
-                                          "dense_fwd": "dense_fwd_kernel"}[kind],
-               "achieved": round(ach, 2), "peak": peak_gbs, "unit": "GB/s", "frac": round(ach / peak_gbs, 5),
-               "traffic": None, "launches_per_step": len(ev) // reps, "avg_launch_us": round(avg_us, 2),
-               "algorithmic_bytes_per_launch": int(avg_bytes),
-               "note": "batch 256 is launch/latency bound (SURVEY 8d): every kernel moves <= 2 MB"}
-        if self.cfg["ae_form"] == "compact":
-            out["conv1d_fwd_B4096"] = self._probe_big_conv(peak_gbs)
-            out["conv1d_fwd_B65536"] = self._probe_big_conv(peak_gbs, B=65536)
-        return out
-
-    def _probe_big_conv(self, peak_gbs, B=4096, reps=20):
-        """(B,4,256) -> (B,4,256), k=11, stride 1, replicate pad: the decoder's last-block conv1 with its
-        BatchNorm prologue and PReLU+statistics epilogue (SURVEY 8d's example layer), alone at B=4096."""
-        from ._lib import OUT_STATS_PRELU
-        dev = self.device
-        m = self.dec_mod.main[3]
-        x = torch.randn(B, 4, 256, device=dev)
-        part = torch.zeros(RAAE_MAX_PARTS, 4, 2, dtype=torch.float64, device=dev)
-        part[0, :, 0] = x.double().sum((0, 2))
-        part[0, :, 1] = (x.double() ** 2).sum((0, 2))
-        rm, rv = torch.zeros(4, device=dev), torch.ones(4, device=dev)
-        view = ops.make_view(x, None, ops.make_bn(part, 1, B * 256, rm, rv))
-        cv = ops.make_conv(4, 256, 4, 256, 11, 1, 5, True, 1, False)
-        out = torch.empty(B, 4, 256, device=dev)
-        po = torch.zeros(8 * RAAE_MAX_PARTS, 4, 2, dtype=torch.float64, device=dev)
-        for _ in range(3):
-            ops.conv_fwd(view, B, cv, m.conv1.weight, m.conv1.bias, out, OUT_STATS_PRELU, m.relu1.weight, po)
-        e0, e1 = ops.Event(), ops.Event()
-        e0.record()
-        for _ in range(reps):
-            ops.conv_fwd(view, B, cv, m.conv1.weight, m.conv1.bias, out, OUT_STATS_PRELU, m.relu1.weight, po)
-        e1.record()
-        us = 1e3 * e0.elapsed_ms(e1) / reps
-        nbytes = 4 * B * (4 * 256 + 4 * 256) + 4 * (4 * 4 * 11 + 4)
-        ach = nbytes / (us * 1e-6) / 1e9
-        return {"kernel": "conv_fwd_strip_kernel" if B * 4 * 256 >= (1 << 20) else "conv_fwd_tiled_kernel",
-                "batch": B, "avg_launch_us": round(us, 2), "algorithmic_bytes": nbytes,
-                "achieved": round(ach, 1), "unit": "GB/s", "frac": round(ach / peak_gbs, 4)}
+        self.step(b, smooth=True)                  # plan + slab tables exist before the probe arms
+        ops.PROBE = ops.Probe(PROBE_REPS)
+        try:
+            for _ in range(reps):
+                self.step(b, smooth=True)
+            torch.cuda.synchronize()
+            fams = ops.PROBE.summary()
+        finally:
+            ops.PROBE = None
+            self.use_graph = saved_graph
+        total = sum(f["total_us"] for f in fams.values())
+        rows = []
+        for name, f in sorted(fams.items(), key=lambda kv: -kv[1]["total_us"]):
+            ach = f["bytes"] / (f["avg_us"] * 1e-6) / 1e9
+            rows.append({"kernel": name, "share_of_kernel_time": round(f["total_us"] / total, 4),
+                         "launches_per_step": round(f["launches"] / reps, 2), "avg_launch_us": round(f["avg_us"], 2),
+                         "algorithmic_bytes_per_launch": int(f["bytes"]), "achieved": round(ach, 1), "unit": "GB/s",
+                         "frac": round(ach / peak_gbs, 5)})
+        lead = rows[0]
+        return {"bound": "hbm", "kernel": lead["kernel"], "achieved": lead["achieved"], "peak": peak_gbs, "unit": "GB/s",
+                "frac": lead["frac"], "traffic": None, "launches_per_step": lead["launches_per_step"],
+                "avg_launch_us": lead["avg_launch_us"], "algorithmic_bytes_per_launch": lead["algorithmic_bytes_per_launch"],
+                "batch": b, "kernel_time_us_per_step": round(total / reps, 1), "top_kernels": rows[:top],
+                "all_kernels": {r["kernel"]: [r["share_of_kernel_time"], r["avg_launch_us"], r["frac"]] for r in rows}}
 
     @_on_stream_io
     def reconstruct(self, spec):

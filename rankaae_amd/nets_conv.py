@@ -150,11 +150,9 @@ class CompactNet:
         """conv parameter gradients -> slabs; records the slab count of every tensor written."""
         eng = self.eng
         ps = [conv.weight, conv.bias] + ([prelu.weight] if prelu is not None else [])
-        nbytes = 4 * b * (cv.Cin * cv.Lin + cv.Cout * cv.Lout) + 4 * (conv.weight.numel() + conv.bias.numel())
         with eng.side_stream():
-            ns = eng.probe_launch("conv_bwd_weight", nbytes, lambda: ops.conv_bwd_weight(
-                go, b, cv, view, eng.gslab(conv.weight), eng.gslab(conv.bias),
-                eng.gslab(prelu.weight) if prelu is not None else None, eng.arena.n))
+            ns = ops.conv_bwd_weight(go, b, cv, view, eng.gslab(conv.weight), eng.gslab(conv.bias),
+                                     eng.gslab(prelu.weight) if prelu is not None else None, eng.arena.n)
         eng.note_slabs(ps, ns)
 
     def _lw(self, go, b, Cc, E, view, Lin, lin, prelu, tag=0):
@@ -171,10 +169,7 @@ class CompactNet:
         try:
             kind, args, nbytes = next(steps)
             while True:
-                if kind == "a":
-                    n = self.eng.probe_launch("block_fwd_a", nbytes, lambda: ops.block_fwd_a(args))
-                else:
-                    n = ops.block_fwd_b(args)
+                n = ops.block_fwd_a(args) if kind == "a" else ops.block_fwd_b(args)
                 kind, args, nbytes = steps.send(n)
         except StopIteration as done:
             return done.value
@@ -222,15 +217,9 @@ class CompactNet:
             fused = self.fused and k.Cin <= 8 and k.Cout <= 8
             if fused:
                 # two kernels per block: everything that only needs bn1, then everything that needs bn2 / bn_excit
-                # algorithmic bytes of phase A: the block input (and its dropout mask) read once, T1, Sh,
-                # E1, E2 written once, weights read once
                 mask_i = self._mask(masks, i, train)
-                nbytes = 4 * b * (k.Cin * k.Lin * (2 if mask_i is not None else 1) + k.Cout * k.L1 +
-                                  (k.Cout * k.Lout if k.cvs is not None else 0) + k.Cin * k.E + k.Cin * k.Lout) + \
-                    4 * (m.conv1.weight.numel() + m.fc1.weight.numel() + m.fc2.weight.numel() +
-                         (m.conv_short.weight.numel() if k.cvs is not None else 0))
                 n1 = yield ("a", ops.block_fwd_a_args(vR(True), mask_i, b, k, m, w.T1, w.Sh, w.E1, w.E2, w.pT1,
-                                                      w.pE2 if k.cve is not None else None), nbytes)
+                                                      w.pE2 if k.cve is not None else None), 0)
                 w.nT1 = w.nE2 = n1
                 v1 = ops.make_view(w.T1, m.relu1.weight, self._bn(m.bn2, w.pT1, w.nT1, b * k.L1, train, True))
                 if k.cve is not None:
@@ -373,11 +362,6 @@ class CompactNet:
                     convs.append((ops.make_grad(w.dSh), k.cvs, vR(), m.conv_short))
                 lins = [(ops.make_grad(dE2), k.Cin, k.Lout, k.E, ops.make_view(w.E1, m.relu_excit_1.weight), m.fc2),
                         (ops.make_grad(w.dE1), k.Cin, k.E, k.Lin, vR(mask), m.fc1)]
-                # algorithmic bytes: every task reads its input view and its output gradient
-                # once and writes one slab of weight + bias gradients
-                nbytes = sum(4 * b * (cv_.Cin * cv_.Lin + cv_.Cout * cv_.Lout) + 4 * (mod.weight.numel() + cv_.Cout)
-                             for _, cv_, _, mod in convs)
-                nbytes += sum(4 * b * c_ * (e_ + l_) + 4 * (e_ * l_ + e_) for _, c_, e_, l_, _, _ in lins)
                 wargs = ops.block_wgrad_args(
                     b, [(g_, cv_, v_, G_(mod.weight), G_(mod.bias)) for g_, cv_, v_, mod in convs],
                     [(g_, c_, e_, l_, v_, G_(mod.weight), G_(mod.bias)) for g_, c_, e_, l_, v_, mod in lins],
@@ -385,8 +369,7 @@ class CompactNet:
                 if eng._branch:
                     eng.join_side_streams()
                     with eng.side_stream():
-                        ns = eng.probe_launch("block_wgrad", nbytes,
-                                              lambda: ops.block_wgrad(b, None, None, eng.arena.n, args=wargs))
+                        ns = ops.block_wgrad(b, None, None, eng.arena.n, args=wargs)
                     note_wgrad((wargs, convs, lins), ns)
                 else:
                     pending = (wargs, convs, lins)

@@ -44,11 +44,13 @@ def _bnp(bn):
 
 
 def dense_fwd(x, B, K, in_kind, slope, bn, mask, w, bias, N, z, out_kind, out_slope=None, out_partials=None):
-    n = C.c_int(0)
-    check(_lib.load().raae_dense_fwd(_ptr(x), B, K, in_kind, _ptr(slope), _bnp(bn), _ptr(mask), _ptr(w), _ptr(bias),
-                                     N, _ptr(z), out_kind, _ptr(out_slope), _ptr(out_partials, torch.float64),
-                                     C.byref(n), _stream()), "raae_dense_fwd")
-    return n.value
+    def launch():
+        n = C.c_int(0)
+        check(_lib.load().raae_dense_fwd(_ptr(x), B, K, in_kind, _ptr(slope), _bnp(bn), _ptr(mask), _ptr(w), _ptr(bias),
+                                         N, _ptr(z), out_kind, _ptr(out_slope), _ptr(out_partials, torch.float64),
+                                         C.byref(n), _stream()), "raae_dense_fwd")
+        return n.value
+    return _probed("dense_fwd_kernel", 4 * (B * K * (2 if mask is not None else 1) + N * K + N + B * N), launch)
 
 
 def dense_fwd_args(x, B, K, in_kind, slope, bn, mask, w, bias, N, z, out_kind, out_slope=None, out_partials=None):
@@ -63,20 +65,30 @@ def dense_fwd_args(x, B, K, in_kind, slope, bn, mask, w, bias, N, z, out_kind, o
     return a
 
 
+def dense_fwd_bytes(a):
+    """Algorithmic bytes of a fused dense layer: input (and its dropout mask) read once, weights and bias once,
+    output written once."""
+    return 4 * (a.B * a.K * (2 if a.mask else 1) + a.N * a.K + a.N + a.B * a.N)
+
+
 def dense_fwd_struct(a):
     """``dense_fwd`` from a ``raae_dense_fwd_t``."""
-    n = C.c_int(0)
-    check(_lib.load().raae_dense_fwd(a.x, a.B, a.K, a.in_kind, a.slope, C.byref(a.bn) if a.has_bn else None, a.mask, a.w,
-                                     a.bias, a.N, a.z, a.out_kind, a.out_slope, a.out_partials, C.byref(n), _stream()),
-          "raae_dense_fwd")
-    return n.value
+    def launch():
+        n = C.c_int(0)
+        check(_lib.load().raae_dense_fwd(a.x, a.B, a.K, a.in_kind, a.slope, C.byref(a.bn) if a.has_bn else None, a.mask,
+                                         a.w, a.bias, a.N, a.z, a.out_kind, a.out_slope, a.out_partials, C.byref(n),
+                                         _stream()), "raae_dense_fwd")
+        return n.value
+    return _probed("dense_fwd_kernel", dense_fwd_bytes(a), launch)
 
 
 def dense_fwd_pair(p, q):
     """Two independent dense layers in one launch; returns both partial-row counts."""
-    n1, n2 = C.c_int(0), C.c_int(0)
-    check(_lib.load().raae_dense_fwd2(C.byref(p), C.byref(q), C.byref(n1), C.byref(n2), _stream()), "raae_dense_fwd2")
-    return n1.value, n2.value
+    def launch():
+        n1, n2 = C.c_int(0), C.c_int(0)
+        check(_lib.load().raae_dense_fwd2(C.byref(p), C.byref(q), C.byref(n1), C.byref(n2), _stream()), "raae_dense_fwd2")
+        return n1.value, n2.value
+    return _probed("dense_fwd2_kernel", dense_fwd_bytes(p) + dense_fwd_bytes(q), launch)
 
 
 def disc_fused(z_real, styles, noise, sigma, mask1, mask2, layers, alpha, n_real, n_fake, ns, gslab, slab_stride,
@@ -96,19 +108,31 @@ def disc_fused(z_real, styles, noise, sigma, mask1, mask2, layers, alpha, n_real
     a.dw3, a.db3 = gslab(l3.w).data_ptr(), gslab(l3.b).data_ptr()
     a.slab_stride = slab_stride
     a.dstyles, a.partial, a.ticket, a.loss = dstyles.data_ptr(), partial.data_ptr(), ticket.data_ptr(), loss.data_ptr()
-    n = C.c_int(0)
-    check(_lib.load().raae_disc_fused(C.byref(a), C.byref(n), _stream()), "raae_disc_fused")
-    return n.value
+    def launch():
+        n = C.c_int(0)
+        check(_lib.load().raae_disc_fused(C.byref(a), C.byref(n), _stream()), "raae_disc_fused")
+        return n.value
+    rows = n_real + n_fake
+    nmask = (1 if mask1 is not None else 0) + (1 if mask2 is not None else 0)
+    # z_real / styles (+ noise) read, masks read, dstyles written, weights read + one gradient slab written per workgroup
+    nbytes = 4 * (rows * ns * (2 if noise is not None else 1) + rows * l1.N * nmask + n_fake * ns +
+                  2 * (l1.w.numel() + l2.w.numel() + l3.w.numel() + 3 * l1.N + 1))
+    return _probed("disc_fused_kernel", nbytes, launch)
 
 
 def dense_bwd(g, g_kind, g_partials, g_nparts, zout, out_slope, out_bn, B, N, x, K, in_kind, slope, bn, mask, w,
               dw, db, dslope, slab_stride, dx=None, dx_partials=None):
-    n = C.c_int(0)
-    check(_lib.load().raae_dense_bwd(_ptr(g), g_kind, _ptr(g_partials, torch.float64), g_nparts, _ptr(zout),
-                                     _ptr(out_slope), _bnp(out_bn), B, N, _ptr(x), K, in_kind, _ptr(slope), _bnp(bn),
-                                     _ptr(mask), _ptr(w), _ptr(dw), _ptr(db), _ptr(dslope), slab_stride, C.byref(n),
-                                     _ptr(dx), _ptr(dx_partials, torch.float64), _stream()), "raae_dense_bwd")
-    return n.value
+    def launch():
+        n = C.c_int(0)
+        check(_lib.load().raae_dense_bwd(_ptr(g), g_kind, _ptr(g_partials, torch.float64), g_nparts, _ptr(zout),
+                                         _ptr(out_slope), _bnp(out_bn), B, N, _ptr(x), K, in_kind, _ptr(slope), _bnp(bn),
+                                         _ptr(mask), _ptr(w), _ptr(dw), _ptr(db), _ptr(dslope), slab_stride, C.byref(n),
+                                         _ptr(dx), _ptr(dx_partials, torch.float64), _stream()), "raae_dense_bwd")
+        return n.value
+    # output gradient and raw output read, input (+ mask) read, input gradient written, weights read, one slab written
+    nbytes = 4 * (B * N * (2 if zout is not None else 1) + B * K * (2 if mask is not None else 1) +
+                  (B * K if dx is not None else 0) + 2 * N * K + 2 * N)
+    return _probed("dense_bwd_kernel", nbytes, launch)
 
 
 def style_bn_fwd(z, B, Cc, bn, styles):
@@ -125,9 +149,11 @@ def rank_loss_work_bytes(B, n_aux):
 
 
 def rank_loss_fwd_bwd(d, ldd, z, ldz, B, n_aux, activate, work, loss, dz):
-    check(_lib.load().raae_rank_loss_fwd_bwd(_ptr(d), ldd, _ptr(z), ldz, B, n_aux, 1 if activate else 0,
-                                             _ptr(work, None), _ptr(loss), _ptr(dz), _stream()),
-          "raae_rank_loss_fwd_bwd")
+    def launch():
+        check(_lib.load().raae_rank_loss_fwd_bwd(_ptr(d), ldd, _ptr(z), ldz, B, n_aux, 1 if activate else 0,
+                                                 _ptr(work, None), _ptr(loss), _ptr(dz), _stream()),
+              "raae_rank_loss_fwd_bwd")
+    _probed("rank_pairs_kernel", 4 * B * n_aux * 3, launch)      # O(B) bytes for B^2 n_aux pair operations: VALU-bound
 
 
 def style_metrics(z, n, k, a_coef, work, out):
@@ -200,10 +226,12 @@ def gather_batch(spec, aux, idx, cursor, noise, spec_noise, B, L, n_aux, spec_ou
 
 
 def adam_step(p, m, v, g_slabs, slab_stride, seg_nslab, n, hyper, step, decoupled, max_nslab=512):
-    check(_lib.load().raae_adam_step(_ptr(p), _ptr(m), _ptr(v), _ptr(g_slabs), slab_stride,
-                                     _ptr(seg_nslab, torch.int16), n, _ptr(hyper, torch.float64),
-                                     _ptr(step, torch.int32), 1 if decoupled else 0, int(max_nslab), _stream()),
-          "raae_adam_step")
+    def launch():
+        check(_lib.load().raae_adam_step(_ptr(p), _ptr(m), _ptr(v), _ptr(g_slabs), slab_stride,
+                                         _ptr(seg_nslab, torch.int16), n, _ptr(hyper, torch.float64),
+                                         _ptr(step, torch.int32), 1 if decoupled else 0, int(max_nslab), _stream()),
+              "raae_adam_step")
+    _probed("adam_kernel", 28 * n, launch)       # p, m, v read + written, one gradient read (28 B / parameter)
 
 
 def slab_reduce(g_slabs, slab_stride, seg_nslab, n, out, max_nslab=512):
@@ -258,6 +286,84 @@ class Event:
         return ms.value
 
 
+# ------------------------------------------------------------------ roofline probe (bench.py)
+class Probe:
+    """While ``ops.PROBE`` holds one of these, every kernel launch that goes through a probed wrapper is followed
+    by ``reps`` identical launches captured into a small hipGraph and replayed between two HIP events recorded on the
+    stream the kernel is launched on (a single bracketed eager launch would measure the host's submission latency,
+    tens of microseconds, not the kernel).  ``records[family] = [(event0, event1, algorithmic bytes)]``."""
+
+    def __init__(self, reps=10):
+        self.reps, self.records, self.graphs, self.busy = reps, {}, [], False
+
+    def summary(self):
+        """``{family: dict(launches, avg_us, bytes)}`` -- call after a device synchronisation."""
+        out = {}
+        for fam, recs in self.records.items():
+            us = [1e3 * a.elapsed_ms(z) / self.reps for a, z, _ in recs]
+            out[fam] = {"launches": len(recs), "avg_us": sum(us) / len(us), "total_us": sum(us),
+                        "bytes": sum(n for *_, n in recs) / len(recs)}
+        return out
+
+
+PROBE = None
+
+
+def _probed(family, nbytes, launch):
+    out = launch()
+    pr = PROBE
+    if pr is None or pr.busy:
+        return out
+    pr.busy = True
+    try:
+        g = Graph()
+        g.begin()
+        for _ in range(pr.reps):
+            launch()
+        g.end()
+        e0, e1 = Event(), Event()
+        e0.record()
+        g.launch()
+        e1.record()
+        pr.graphs.append(g)
+        pr.records.setdefault(family, []).append((e0, e1, int(nbytes)))
+    finally:
+        pr.busy = False
+    return out
+
+
+def block_bytes(kernel, k, B, mask=False, need_dx=True, input_bn=True):
+    """ALGORITHMIC bytes of one launch of a fused residual-block kernel (SURVEY.md 8d's rule: every tensor the
+    kernel must read or write counted once, fp32, weights once, no extra passes): ``k`` is the block's static
+    shape (nets_conv.Block).  Per sample, with X [Cin,Lin], T1 [Cout,L1], everything else [C,Lout]:
+      fwd_a  reads X (+ dropout mask)              writes T1, Sh (conv_short), E1, E2
+      fwd_b  reads T1, E2, Sh | X                  writes T2, E3 (conv_excit), Y
+      bwd_b  reads gY (+ Y behind a BatchNorm), T2, Sh, E3 | E2, T1 (, E2)      writes dT2, dSh, dEx, dBn2 (, dBnE)
+      bwd_a  reads dBn2, T1, dSh, dBnE + E2 | dE2, E1 (, mask, X)               writes dT1 (, dE2), dE1, dR
+    """
+    ci_lin, co_l1, co_lo, ci_lo, ci_e = k.Cin * k.Lin, k.Cout * k.L1, k.Cout * k.Lout, k.Cin * k.Lout, k.Cin * k.E
+    short, excit = k.cvs is not None, k.cve is not None
+    nw = lambda mod: 0 if mod is None else mod.weight.numel() + (0 if mod.bias is None else mod.bias.numel())
+    m = k.m
+    if kernel == "fwd_a":
+        per = ci_lin * (2 if mask else 1) + co_l1 + (co_lo if short else 0) + ci_e + ci_lo
+        w = nw(m.conv1) + nw(m.conv_short) + nw(m.fc1) + nw(m.fc2)
+    elif kernel == "fwd_b":
+        per = co_l1 + ci_lo + (co_lo if short else ci_lin) + co_lo * (3 if excit else 2)
+        w = nw(m.conv2) + nw(m.conv_excit)
+    elif kernel == "bwd_b":
+        per = co_lo * (2 if input_bn else 1) + co_lo * (3 if short else 2) + co_l1 + (ci_lo if excit else 0) + \
+            3 * co_lo + co_l1 + (ci_lo if excit else 0)
+        w = nw(m.conv2) + nw(m.conv_excit)
+    elif kernel == "bwd_a":
+        per = 2 * co_l1 + co_lo + (2 * ci_lo if excit else ci_lo) + ci_e + (ci_lin if mask else 0) + \
+            co_l1 + (ci_lo if excit else 0) + ci_e + ((ci_lin * (2 if input_bn else 1)) if need_dx else 0)
+        w = nw(m.conv1) + nw(m.conv_short) + nw(m.fc1) + nw(m.fc2)
+    else:
+        raise ValueError(kernel)
+    return 4 * (B * per + w)
+
+
 # ------------------------------------------------------------------ conv-network ops
 def make_view(raw, slope=None, bn=None, mask=None):
     v = _lib.ViewT()
@@ -298,27 +404,41 @@ def make_conv(Cin, Lin, Cout, Lout, K, stride, pad, pad_replicate, groups, trans
     return c
 
 
+def conv_bytes(cv, B, extra_in=0, extra_out=0):
+    """``4 B (Cin Lin + Cout Lout) + 4 (weights + bias)`` per Conv1d call; ``extra_*``: further whole
+    input- / output-sized tensors the call must touch (a mask, the raw output behind an activation gradient, ...)."""
+    return 4 * B * (cv.Cin * cv.Lin * (1 + extra_in) + cv.Cout * cv.Lout * (1 + extra_out)) + \
+        4 * (cv.Cout * (cv.Cin // cv.groups) * cv.K + cv.Cout)
+
+
 def conv_fwd(view, B, cv, w, bias, out, stats_kind=0, out_slope=None, out_partials=None, act=0):
-    n = C.c_int(0)
-    check(_lib.load().raae_conv_fwd(C.byref(view), B, C.byref(cv), _ptr(w), _ptr(bias), _ptr(out), stats_kind,
-                                    _ptr(out_slope), _ptr(out_partials, torch.float64), C.byref(n), act, _stream()),
-          "raae_conv_fwd")
-    return n.value
+    def launch():
+        n = C.c_int(0)
+        check(_lib.load().raae_conv_fwd(C.byref(view), B, C.byref(cv), _ptr(w), _ptr(bias), _ptr(out), stats_kind,
+                                        _ptr(out_slope), _ptr(out_partials, torch.float64), C.byref(n), act, _stream()),
+              "raae_conv_fwd")
+        return n.value
+    return _probed("conv_fwd (per-layer)", conv_bytes(cv, B, extra_in=1 if view.mask else 0), launch)
 
 
 def conv_bwd_data(go, B, cv, w, view, din, accumulate, din_partials=None):
-    n = C.c_int(0)
-    check(_lib.load().raae_conv_bwd_data(C.byref(go), B, C.byref(cv), _ptr(w), C.byref(view), _ptr(din),
-                                         1 if accumulate else 0, _ptr(din_partials, torch.float64), C.byref(n),
-                                         _stream()), "raae_conv_bwd_data")
-    return n.value
+    def launch():
+        n = C.c_int(0)
+        check(_lib.load().raae_conv_bwd_data(C.byref(go), B, C.byref(cv), _ptr(w), C.byref(view), _ptr(din),
+                                             1 if accumulate else 0, _ptr(din_partials, torch.float64), C.byref(n),
+                                             _stream()), "raae_conv_bwd_data")
+        return n.value
+    return _probed("conv_bwd_data (per-layer)", conv_bytes(cv, B, extra_in=1 if din_partials is not None else 0,
+                                                           extra_out=1 if go.raw else 0), launch)
 
 
 def conv_bwd_weight(go, B, cv, view, dw, dbias, dslope, slab_stride):
-    n = C.c_int(0)
-    check(_lib.load().raae_conv_bwd_weight(C.byref(go), B, C.byref(cv), C.byref(view), _ptr(dw), _ptr(dbias),
-                                           _ptr(dslope), slab_stride, C.byref(n), _stream()), "raae_conv_bwd_weight")
-    return n.value
+    def launch():
+        n = C.c_int(0)
+        check(_lib.load().raae_conv_bwd_weight(C.byref(go), B, C.byref(cv), C.byref(view), _ptr(dw), _ptr(dbias),
+                                               _ptr(dslope), slab_stride, C.byref(n), _stream()), "raae_conv_bwd_weight")
+        return n.value
+    return _probed("conv_bwd_weight (per-layer)", conv_bytes(cv, B, extra_out=1 if go.raw else 0), launch)
 
 
 def lenlin_fwd(view, B, Cc, Lin, w, bias, E, out, stats_kind=0, out_slope=None, out_partials=None):
@@ -377,22 +497,27 @@ def block_fwd_a_args(view_in, mask, B, k, m, T1, Sh, E1, E2, pT1, pE2):
     a.wf1, a.bf1, a.se1 = _p(m.fc1.weight), _p(m.fc1.bias), _p(m.relu_excit_1.weight)
     a.wf2, a.bf2, a.se2 = _p(m.fc2.weight), _p(m.fc2.bias), _p(m.relu_excit_2.weight)
     a.T1, a.Sh, a.E1, a.E2, a.pT1, a.pE2 = _p(T1), _p(Sh), _p(E1), _p(E2), _p(pT1), _p(pE2)
+    a.nbytes = block_bytes("fwd_a", k, B, mask=mask is not None)
     return a
 
 
 def block_fwd_a(a):
     """Fused forward phase A of a residual block; returns the number of partial-statistic rows written."""
-    n = C.c_int(0)
-    check(_lib.load().raae_block_fwd_a(C.byref(a), C.byref(n), _stream()), "raae_block_fwd_a")
-    return n.value
+    def launch():
+        n = C.c_int(0)
+        check(_lib.load().raae_block_fwd_a(C.byref(a), C.byref(n), _stream()), "raae_block_fwd_a")
+        return n.value
+    return _probed("block_fwd_a_kernel", a.nbytes, launch)
 
 
 def block_fwd_pair(kind, x, y):
     """Phase ``kind`` ("a" / "b") of two independent blocks in one launch; returns both row counts."""
-    n1, n2 = C.c_int(0), C.c_int(0)
-    fn = _lib.load().raae_block_fwd_a2 if kind == "a" else _lib.load().raae_block_fwd_b2
-    check(fn(C.byref(x), C.byref(y), C.byref(n1), C.byref(n2), _stream()), f"raae_block_fwd_{kind}2")
-    return n1.value, n2.value
+    def launch():
+        n1, n2 = C.c_int(0), C.c_int(0)
+        fn = _lib.load().raae_block_fwd_a2 if kind == "a" else _lib.load().raae_block_fwd_b2
+        check(fn(C.byref(x), C.byref(y), C.byref(n1), C.byref(n2), _stream()), f"raae_block_fwd_{kind}2")
+        return n1.value, n2.value
+    return _probed(f"block_fwd_{kind}2_kernel", x.nbytes + y.nbytes, launch)
 
 
 def block_fwd_b_args(vT1, vE2, vR, B, k, m, Sh, T2, E3, Y, pY):
@@ -411,13 +536,16 @@ def block_fwd_b_args(vT1, vE2, vR, B, k, m, Sh, T2, E3, Y, pY):
         a.Sh, a.ss = _p(Sh), _p(m.relu_short.weight)
     a.w2, a.b2, a.slope2 = _p(m.conv2.weight), _p(m.conv2.bias), _p(m.relu2.weight)
     a.T2, a.E3, a.Y, a.pY = _p(T2), _p(E3), _p(Y), _p(pY)
+    a.nbytes = block_bytes("fwd_b", k, B)
     return a
 
 
 def block_fwd_b(a):
-    n = C.c_int(0)
-    check(_lib.load().raae_block_fwd_b(C.byref(a), C.byref(n), _stream()), "raae_block_fwd_b")
-    return n.value
+    def launch():
+        n = C.c_int(0)
+        check(_lib.load().raae_block_fwd_b(C.byref(a), C.byref(n), _stream()), "raae_block_fwd_b")
+        return n.value
+    return _probed("block_fwd_b_kernel", a.nbytes, launch)
 
 
 def block_bwd_b(gy, vT1, vE2, B, k, m, w, slab_stride, gslab, wgrad=None):
@@ -444,14 +572,20 @@ def block_bwd_b(gy, vT1, vE2, B, k, m, w, slab_stride, gslab, wgrad=None):
     a.dT2, a.dSh, a.dEx, a.dBn2, a.pdBn2 = _p(w.dT2), _p(w.dSh), _p(w.dEx), _p(w.dBn2), _p(w.pdBn2)
     a.dslope2 = _p(gslab(m.relu2.weight))
     a.slab_stride = slab_stride
+    nbytes = block_bytes("bwd_b", k, B, input_bn=bool(gy.has_bn))
     if wgrad is not None:          # the following block's weight-gradient tasks ride in the same launch
-        n, ns = C.c_int(0), (C.c_int * 6)()
-        check(_lib.load().raae_block_bwd_b_wgrad(C.byref(a), C.byref(wgrad), C.byref(n), ns, _stream()),
-              "raae_block_bwd_b_wgrad")
-        return n.value, list(ns)[:wgrad.n_conv + wgrad.n_lin]
-    n = C.c_int(0)
-    check(_lib.load().raae_block_bwd_b(C.byref(a), C.byref(n), _stream()), "raae_block_bwd_b")
-    return n.value
+        def launch2():
+            n, ns = C.c_int(0), (C.c_int * 6)()
+            check(_lib.load().raae_block_bwd_b_wgrad(C.byref(a), C.byref(wgrad), C.byref(n), ns, _stream()),
+                  "raae_block_bwd_b_wgrad")
+            return n.value, list(ns)[:wgrad.n_conv + wgrad.n_lin]
+        return _probed("block_bwd_b_wgrad_kernel", nbytes + wgrad.nbytes, launch2)
+
+    def launch():
+        n = C.c_int(0)
+        check(_lib.load().raae_block_bwd_b(C.byref(a), C.byref(n), _stream()), "raae_block_bwd_b")
+        return n.value
+    return _probed("block_bwd_b_kernel", nbytes, launch)
 
 
 def block_bwd_a(g1, ge, view_in, mask, B, k, m, w, dE2, dR, pdR, slab_stride, gslab):
@@ -474,9 +608,13 @@ def block_bwd_a(g1, ge, view_in, mask, B, k, m, w, dE2, dR, pdR, slab_stride, gs
     if k.cve is not None:
         a.dslope_e2 = _p(gslab(m.relu_excit_2.weight))
     a.slab_stride = slab_stride
-    n = C.c_int(0)
-    check(_lib.load().raae_block_bwd_a(C.byref(a), C.byref(n), _stream()), "raae_block_bwd_a")
-    return n.value
+
+    def launch():
+        n = C.c_int(0)
+        check(_lib.load().raae_block_bwd_a(C.byref(a), C.byref(n), _stream()), "raae_block_bwd_a")
+        return n.value
+    return _probed("block_bwd_a_kernel", block_bytes("bwd_a", k, B, mask=mask is not None, need_dx=dR is not None,
+                                                     input_bn=pdR is not None), launch)
 
 
 def block_wgrad_args(B, conv_tasks, lin_tasks, slab_stride):
@@ -489,6 +627,11 @@ def block_wgrad_args(B, conv_tasks, lin_tasks, slab_stride):
     for i, (go, Cc, E, Lin, view, dw, db) in enumerate(lin_tasks):
         a.lin[i].go, a.lin[i].C, a.lin[i].E, a.lin[i].Lin, a.lin[i].inp = go, Cc, E, Lin, view
         a.lin[i].dw, a.lin[i].dbias = dw.data_ptr(), db.data_ptr()
+    # algorithmic bytes: every task reads its input view and its output gradient once and writes one slab
+    # of weight + bias gradients
+    a.nbytes = sum(4 * B * (cv.Cin * cv.Lin + cv.Cout * cv.Lout) + 4 * (cv.Cout * (cv.Cin // cv.groups) * cv.K + cv.Cout)
+                   for _, cv, _, _, _ in conv_tasks) + \
+        sum(4 * B * Cc * (E + Lin) + 4 * (E * Lin + E) for _, Cc, E, Lin, _, _, _ in lin_tasks)
     return a
 
 
@@ -496,6 +639,9 @@ def block_wgrad(B, conv_tasks, lin_tasks, slab_stride, args=None):
     """``conv_tasks``: [(grad, conv_desc, view, dw, dbias)], ``lin_tasks``: [(grad, C, E, Lin, view, dw, dbias)].
     One launch; returns the slab count per task (conv tasks first)."""
     a = args if args is not None else block_wgrad_args(B, conv_tasks, lin_tasks, slab_stride)
-    ns = (C.c_int * 6)()
-    check(_lib.load().raae_block_wgrad(C.byref(a), ns, _stream()), "raae_block_wgrad")
-    return list(ns)[:a.n_conv + a.n_lin]
+
+    def launch():
+        ns = (C.c_int * 6)()
+        check(_lib.load().raae_block_wgrad(C.byref(a), ns, _stream()), "raae_block_wgrad")
+        return list(ns)[:a.n_conv + a.n_lin]
+    return _probed("wgrad_multi_kernel", a.nbytes, launch)

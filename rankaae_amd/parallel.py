@@ -38,3 +38,54 @@ def allreduce_mean_(buf, group=None):
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
         buf.mul_(1.0 / world)
     return buf
+
+
+def epoch_schedule(n_rows, world, b):
+    """The steps of one data-parallel epoch as ``[(rows per rank, global offset, global rows)]``: every full global
+    batch of ``world * b`` rows, then -- the reference keeps the last partial batch (``drop_last=False``,
+    sc/clustering/dataloader.py:71) -- the tail split evenly over the ranks (``tail // world`` rows each; at most
+    ``world - 1`` rows of the permutation stay unused, none when world == 1; a tail of fewer than 2 rows per rank is
+    dropped because training-mode BatchNorm needs two).  Rank r steps rows
+    ``perm[offset + r * rows : offset + (r + 1) * rows]`` of each entry."""
+    steps, off = [], 0
+    for _ in range(n_rows // (world * b)):
+        steps.append((b, off, world * b))
+        off += world * b
+    tail = (n_rows - off) // world
+    if tail >= 2 or (world == 1 and tail == 1):
+        steps.append((tail, off, world * tail))
+    return steps
+
+
+def broadcast_from_rank0(values, device, group=None):
+    """A short list of floats, rank 0's copy on every rank (float64, exact)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return list(values)
+    t = torch.tensor(list(values), dtype=torch.float64)
+    if dist.get_backend(group) == "nccl":
+        t = t.to(device)
+    dist.broadcast(t, src=0, group=group)
+    return t.cpu().tolist()
+
+
+def broadcast_tensor_from_rank0(t, device, group=None):
+    """An int64 / float CPU tensor (e.g. the epoch permutation): rank 0's values on every rank."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return t
+    buf = t.to(device) if dist.get_backend(group) == "nccl" else t.clone()
+    dist.broadcast(buf, src=0, group=group)
+    return buf.cpu()
+
+
+def average_(tensors, group=None):
+    """In-place mean over ranks of a list of small tensors (BatchNorm running statistics at the end of an epoch: the
+    replicas keep per-replica statistics, DDP semantics, and meet before validation so that every rank validates --
+    and schedules its learning rates -- on the same numbers)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1 or not tensors:
+        return
+    flat = torch.cat([t.reshape(-1).float() for t in tensors])
+    allreduce_mean_(flat, group)
+    off = 0
+    for t in tensors:
+        t.copy_(flat[off:off + t.numel()].view_as(t))
+        off += t.numel()

@@ -9,7 +9,15 @@ runs as HIP kernels through ``rankaae_amd.engine.StepEngine``; there is no PyTor
 Build-only config keys (all optional, defaults preserve reference behaviour):
   ``rng_mode``  "philox" (device Philox tape, default) | "host" (reference-order CPU draws; parity)
   ``use_graph`` True: replay one captured hipGraph per step
-  ``seed``      Philox seed (``rng_mode: philox``)
+  ``seed``      Philox seed (``rng_mode: philox``); default: drawn from the global torch generator, i.e. a different
+                random stream for every trial of a run, as in the reference (whose trials are independent draws)
+
+Data parallel (the north star's replacement of the ipyparallel trial farm): started under
+``torch.distributed.run`` (WORLD_SIZE > 1) every rank builds the same ``Trainer``; rank r steps rows
+``[r*b, (r+1)*b)`` of each global batch of ``W*b`` rows of the SAME epoch permutation (rank 0's), the five per-phase
+gradient arenas are averaged over RCCL inside the step, BatchNorm running statistics are averaged over the ranks
+before each validation, the metrics list is rank 0's on every rank (so the five ReduceLROnPlateau schedules stay in
+lockstep), and only rank 0 writes ``losses.csv`` / checkpoints / ``final.pt``.
 """
 import copy
 import logging
@@ -72,15 +80,39 @@ class Trainer:
         if self.optimizer_name not in OPTIM_NAMES:
             raise ValueError(f"optimizer_name must be one of {OPTIM_NAMES}")
         cfg = config_parameters.to_dict()
+        self.world, self.rank, self.pg = self._data_parallel_setup(device)
+        # one draw from the global generator per trial (also when `seed` is given, so that the generator's state
+        # does not depend on the key): trials of one run then use different noise / dropout / latent streams
+        drawn = int(torch.empty((), dtype=torch.int64).random_().item()) & 0x7fffffff if cfg.get("rng_mode", "philox") == "philox" else 0
+        seed = int(cfg.get("seed", drawn)) + self.rank
         self.engine = StepEngine(encoder, decoder, discriminator, cfg, device,
-                                 rng_mode=cfg.get("rng_mode", "philox"), seed=cfg.get("seed", 0),
-                                 use_graph=cfg.get("use_graph", True))
+                                 rng_mode=cfg.get("rng_mode", "philox"), seed=seed,
+                                 use_graph=cfg.get("use_graph", True), world_size=self.world, rank=self.rank,
+                                 process_group=self.pg)
         ds = train_loader.dataset
         if ds.aux is None:
             raise ValueError("n_aux: 0 is not reachable in the reference (SURVEY.md finding 4)")
         self.engine.set_data(ds.spec, ds.aux)
         self.load_optimizers()
         self.load_schedulers()
+
+    @staticmethod
+    def _data_parallel_setup(device):
+        """``(world, rank, process group)``: data parallel when started under ``torch.distributed.run``.  The process
+        group is created here if the launcher's caller has not done so (backend RCCL; ``RANKAAE_DP_BACKEND=gloo``
+        rehearses the path with several ranks on one GPU)."""
+        import torch.distributed as dist
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world == 1 and not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return 1, 0, None
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            backend = os.environ.get("RANKAAE_DP_BACKEND", "nccl")
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=device)
+            else:
+                dist.init_process_group(backend)
+        return dist.get_world_size(), dist.get_rank(), None
 
     def load_optimizers(self):
         self.optimizers = self.engine.opts
@@ -106,30 +138,48 @@ class Trainer:
         return out
 
     def train(self, callback=None):
+        from .parallel import average_, broadcast_from_rank0, broadcast_tensor_from_rank0, epoch_schedule
         eng = self.engine
+        lead = self.rank == 0
         best_combined_metric = 10.0
         chkpt_dir = f"{self.work_dir}/checkpoints"
-        os.makedirs(chkpt_dir, exist_ok=True)
+        if lead:
+            os.makedirs(chkpt_dir, exist_ok=True)
         best_chpt_file, metrics = None, None
-        self.loss_logger.info(
-            "Epoch,Train_D,Val_D,Train_G,Val_G,Train_Aux,Val_Aux,Train_Recon,"
-            "Val_Recon,Train_Smooth,Val_Smooth,Train_Mutual_Info,Val_Mutual_Info")
+        if lead:
+            self.loss_logger.info(
+                "Epoch,Train_D,Val_D,Train_G,Val_G,Train_Aux,Val_Aux,Train_Recon,"
+                "Val_Recon,Train_Smooth,Val_Smooth,Train_Mutual_Info,Val_Mutual_Info")
         vds = self.val_loader.dataset
         val_spec = torch.as_tensor(vds.spec, dtype=torch.float32).contiguous().to(self.device)
         val_aux = torch.as_tensor(vds.aux, dtype=torch.float32).contiguous().to(self.device)
         n_train, bs = len(self.train_loader.dataset), self.train_loader.batch_size
-        n_batch = len(self.train_loader)
+        # single GPU: every batch of the reference's loader incl. the ragged last one; data parallel: every full
+        # global batch of world * bs rows, the tail split evenly over the ranks (parallel.epoch_schedule)
+        schedule = epoch_schedule(n_train, self.world, bs)
+        n_batch = len(schedule)
+        bn_buffers = [b_ for mod in (self.encoder, self.decoder) for name, b_ in mod.named_buffers()
+                      if name.endswith("running_mean") or name.endswith("running_var")]
         for epoch in range(self.max_epoch):
             alpha_ = alpha(epoch / self.max_epoch, self.alpha_flat_step, self.alpha_limit)
-            eng.set_epoch(self.train_loader.epoch_permutation(), alpha_)
+            perm = broadcast_tensor_from_rank0(self.train_loader.epoch_permutation(), self.device, self.pg)
+            eng.set_epoch(perm, alpha_)
             smooth = epoch < self.epoch_stop_smooth
-            for ib in range(n_batch):
-                eng.step(min(bs, n_train - ib * bs), smooth=smooth)
+            prev_rows = None
+            for rows, off, global_rows in schedule:
+                if self.world > 1 and rows != prev_rows:      # first step of the epoch, and again at the tail
+                    eng.seek(off + self.rank * rows, global_rows)
+                prev_rows = rows
+                eng.step(rows, smooth=smooth)
             tl = eng.losses()
             if not smooth:
                 tl["smooth"] = 0.0
+            if self.world > 1:
+                with torch.cuda.stream(eng.stream):
+                    average_(bn_buffers, self.pg)
+                eng.stream.synchronize()
             z, vl = eng.validate(val_spec, val_aux)
-            if epoch % 10 == 0:
+            if epoch % 10 == 0 and lead:
                 self.loss_logger.info(
                     f"{epoch:d},\t"
                     f"{tl['adversarial']:.6f},\t{vl['adversarial']:.6f},\t"
@@ -145,18 +195,21 @@ class Trainer:
             style_coupling = np.max(np.fabs(style_rho))
             metrics = [float(np.min(style_shapiro)), vl["recon"], avg_mutual_info, float(style_coupling),
                        vl["kendall"]]
+            metrics = broadcast_from_rank0(metrics, self.device, self.pg)     # no-op on one GPU
             combined_metric = -(np.array(self.metric_weights) * np.array(metrics)).sum()
             if combined_metric > best_combined_metric:
                 best_combined_metric = combined_metric
                 best_chpt_file = f"{chkpt_dir}/epoch_{epoch:06d}_loss_{combined_metric:07.6g}.pt"
-                torch.save(self._model_dict(), best_chpt_file)
+                if lead:
+                    torch.save(self._model_dict(), best_chpt_file)
             for sch in self.schedulers.values():
                 sch.step(combined_metric)
             if callback is not None:
                 callback(epoch, metrics)
-        torch.save(self._model_dict(), f"{self.work_dir}/final.pt")
-        if best_chpt_file is not None:
-            shutil.copy2(best_chpt_file, f"{self.work_dir}/best.pt")
+        if lead:
+            torch.save(self._model_dict(), f"{self.work_dir}/final.pt")
+            if best_chpt_file is not None:
+                shutil.copy2(best_chpt_file, f"{self.work_dir}/best.pt")
         return metrics
 
     @classmethod

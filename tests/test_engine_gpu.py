@@ -114,36 +114,6 @@ def rel_close(a, b, tol, what):
     assert abs(a - b) <= tol * abs(b) + 1e-7, f"{what}: hip {a!r} vs ref {b!r} (rel {abs(a - b) / (abs(b) + 1e-30):.2e})"
 
 
-def oracle_first_step(g, spec, aux, mode, alpha_=0.0):
-    """The oracle's first training step from the fixture's seed; ``mode`` moves every input spectrum value by one
-    float32 ulp (+1: up, -1: down, >= 2: a random up/down pattern seeded with ``mode``; 0: unperturbed)."""
-    cfg = g["config"]
-    s32 = np.asarray(spec, dtype=np.float32)
-    up, down = np.nextafter(s32, np.float32(np.inf)), np.nextafter(s32, np.float32(-np.inf))
-    if mode == 1:
-        s32 = up
-    elif mode == -1:
-        s32 = down
-    elif mode >= 2:
-        s32 = np.where(np.random.default_rng(mode).integers(0, 2, s32.shape).astype(bool), up, down)
-    torch.manual_seed(g["model_seed"])
-    tr = ref_train.OracleTrainer(s32.astype(np.float64), aux, cfg)
-    for m in (tr.encoder, tr.decoder, tr.discriminator):
-        m.train()
-    rows = ref_train.epoch_permutation(len(tr.train_spec)).numpy()[:cfg["batch_size"]]
-    epoch = 0 if 0 < cfg.get("epoch_stop_smooth", 500) else 10 ** 9
-    return tr.train_step(torch.tensor(tr.train_spec[rows], dtype=torch.float32),
-                         torch.tensor(tr.train_aux[rows], dtype=torch.float32), alpha_, epoch)
-
-
-def derived_bounds(g, spec, aux, keys, modes=(1, -1, 2, 3)):
-    """``(oracle losses, {key: bound})``: 3x the largest move of the oracle's own first-step loss under one-ulp
-    perturbations of its input, plus a 1e-4 relative floor."""
-    base = oracle_first_step(g, spec, aux, 0)
-    pert = [oracle_first_step(g, spec, aux, m) for m in modes]
-    return base, {k: 3.0 * max(abs(p[k] - base[k]) for p in pert) + 1e-4 * abs(base[k]) + 1e-7 for k in keys}
-
-
 @pytest.mark.parametrize("case", ["fc_small", "fc_c2", "fc_adam_nodrop", "fc_512_aux12", "compact_small", "compact_c2"])
 def test_p1_first_step_matches_reference_golden(case):
     g, cfg, spec, aux = load_case(case)
@@ -157,7 +127,7 @@ def test_p1_first_step_matches_reference_golden(case):
     eng.step(cfg["batch_size"], smooth=smooth)
     got = eng.losses()
     keys = [k for k in KEYS if not (k == "smooth" and not smooth)]
-    base, bound = derived_bounds(g, spec, aux, keys)
+    base, bound = ref_train.derived_bounds(cfg, g["model_seed"], spec, aux, keys)
     report = []
     for k in keys:
         if k in ("adversarial", "kendall"):     # computed before any ill-conditioned update: the reference's own value
@@ -530,20 +500,30 @@ def test_p4_frozen_weights_free_running_matches_reference_golden(case, tmp_path)
     eng.step, eng.validate = step, validate
     seen = []
     tr.train(callback=lambda ep, m: seen.append([float(x) for x in m]))
-    worst = {}
+    worst, bad = {}, []
+    n_train, n_val, _ = ref_train.split_rows(len(spec))
+    bs = cfg["batch_size"]
+    rows_of_call = ([bs] * (n_train // bs) + ([n_train % bs] if n_train % bs else []) + [n_val]) * cfg["max_epoch"]
     for k in KEYS:
         want = np.array(g["loss_calls"][k])
         got = np.array(rec[k])
-        assert got.shape == want.shape, (k, got.shape, want.shape)
+        assert got.shape == want.shape == (len(rows_of_call),), (k, got.shape, want.shape)
         rel = np.abs(got - want) / (np.abs(want) + 1e-30)
         worst[k] = float(rel.max())
-        # rank loss: its weights are ratios of pair COUNTS (functions.py:73-75); a pair whose style difference is
-        # rounding residue may be counted on the other side: one count in ~2000 pairs of a 64-row batch
-        tol = 1e-4 if k != "kendall" else 1e-3
-        assert np.all(np.abs(got - want) <= tol * np.abs(want) + 1e-6), \
-            (case, k, int(rel.argmax()), got[rel.argmax()], want[rel.argmax()])
+        tol = 1e-4 * np.abs(want) + 1e-6
+        if k == "kendall":
+            # The rank loss weighs its concordant pairs by a ratio of pair COUNTS (functions.py:73-75).  A pair whose
+            # style difference is below the fp32 distance of two implementations (styles agree to ~1e-4 behind the
+            # BatchNorms of a 41-row batch) is counted on the other side: each such pair moves c_k by 4 / (b^2 - b)
+            # and the loss by that times the mean concordant product / n_aux (<= 0.25 here).  Up to three such pairs
+            # per call are accepted; the kernel's counts themselves are exact (tests/test_ops_gpu.py::test_rank_loss).
+            b_ = np.array(rows_of_call, dtype=np.float64)
+            tol = tol + 3 * 0.25 * 4.0 / (b_ * b_ - b_)
+        for i in np.nonzero(np.abs(got - want) > tol)[0]:
+            bad.append(f"{k} call {i} ({rows_of_call[i]} rows): hip {got[i]!r} reference {want[i]!r}")
     print(f"\n{case} P4 worst relative deviation per loss over {len(rec['recon'])} calls: "
           + ", ".join(f"{k} {v:.1e}" for k, v in worst.items()))
+    assert not bad, f"{case}:\n" + "\n".join(bad)
     # metrics: [min Shapiro W, val recon, mean train MI, max |Spearman rho|, val rank loss] per epoch
     assert np.allclose(np.array(seen), np.array(g["epoch_metrics"]), rtol=1e-3, atol=1e-5), (seen, g["epoch_metrics"])
     eng.sync_bn_counters()
