@@ -210,6 +210,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-oracle timing (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--roofline-detail", action="store_true", help="roofline probe per block shape (tuning aid)")
     ap.add_argument("--no-epoch", action="store_true", help="skip the epoch-inclusive (validation + metrics) timing")
     ap.add_argument("--no-configs2", action="store_true", help="skip the batch-4096 / 100k-row sub-run (configs[2])")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
@@ -323,7 +324,7 @@ def main():
         # the extras run on ONE GPU only: with several ranks the probe's extra training steps would enter
         # collectives the other ranks never join, and the contract asks for the CPU baseline at N = 1
         if not args.no_roofline and world == 1:
-            line["roofline"] = eng.roofline_probe(b, HBM_PEAK_GBS)
+            line["roofline"] = eng.roofline_probe(b, HBM_PEAK_GBS, detail=args.roofline_detail)
             for r in line["roofline"]["top_kernels"]:
                 r["traffic"] = pmc_traffic(r["kernel"], cfg["ae_form"], b)
             line["roofline"]["traffic"] = line["roofline"]["top_kernels"][0]["traffic"]

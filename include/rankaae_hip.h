@@ -114,6 +114,20 @@ long raae_rank_loss_work_bytes(int B, int n_aux);
 int raae_rank_loss_fwd_bwd(const float* d, int ldd, const float* z, int ldz, int B, int n_aux, int activate,
                            void* work, float* loss, float* dz, void* stream);
 
+/* The same loss over the GLOBAL pairs of a data-parallel batch (what sc/utils/functions.py:63-77 computes on the
+ * whole batch in one process), split per rank: this rank owns rows [row0, row0 + nrows) of the all-gathered
+ * d_all / z_all [n_all][ld] and pairs them with all n_all rows.
+ *   raae_rank_rows_pairs:  the pair pass; totals[64] doubles = this rank's {n+[16], n-[16], S+[16], S-[16]}
+ *   (the caller sums `totals` over the ranks -- one 512-byte all-reduce)
+ *   raae_rank_rows_finish: global loss (identical on every rank) and dz [nrows][ldz] = scale * dL/dz of this
+ *   rank's rows (exact: every pair that contains row i is seen by its owner); scale = number of ranks when the
+ *   parameter gradients are AVERAGED over ranks afterwards.
+ *   work: >= raae_rank_loss_work_bytes(nrows, n_aux) bytes, the same buffer for both calls. */
+int raae_rank_rows_pairs(const float* d_all, int ldd, const float* z_all, int ldz, int n_all, int row0, int nrows,
+                         int n_aux, void* work, double* totals, void* stream);
+int raae_rank_rows_finish(const double* totals, int n_all, int nrows, int n_aux, int activate, float scale,
+                          void* work, float* loss, float* dz, int ldz, void* stream);
+
 /* Model-selection metrics of the validation styles (sc/clustering/trainer.py:286-292: scipy.stats.shapiro on
  * every style column, scipy.stats.spearmanr on every column pair of the host copy), computed where the styles
  * already are.  z [n][k] styles; a_coef: the n/2 Shapiro-Wilk coefficients for this n (Royston AS R94 with the
@@ -389,7 +403,7 @@ int raae_event_destroy(void* ev);
 int raae_stream_sync(void* stream);
 const char* raae_error_string(int code);
 int raae_device_info(int* cu_count, int* lds_bytes, char* name, int name_len);
-#define RAAE_ABI_VERSION 9
+#define RAAE_ABI_VERSION 10
 int raae_abi_version(void);
 /* First 16 hex digits of sha256 over include/rankaae_hip.h + csrc/raae_*.{h,inc,hip} at build time
  * (build.sh); the Python loader recomputes it and refuses a library built from other sources. */

@@ -190,49 +190,62 @@ class OracleTrainer:
         for m in (self.encoder, self.decoder, self.discriminator):
             m.zero_grad()
 
-    def _finish(self, name, loss):
-        loss.backward()
+    def _finish(self, name):
         if self.phase_hook is not None:
             self.phase_hook(name)
         self.optimizers[name].step()
         if self.post_hook is not None:
             self.post_hook(name)
 
-    # trainer.py:103-204 -- one batch through the five phases
-    def train_step(self, spec_in, aux_in, alpha_, epoch=0):
+    def step_phases(self, spec_in, aux_in, alpha_, epoch=0, kendall=None):
+        """The five phases of one batch (trainer.py:103-204) as a generator: after each phase's ``backward`` it
+        yields ``(optimizer name, loss)`` and expects the caller to apply that optimizer before resuming
+        (``train_step`` does exactly that; ``train_step_sharded`` first averages the gradients of several replicas).
+        ``kendall`` not None: before the rank loss the generator yields ``("correlation_styles", (aux, styles))`` and
+        expects the loss tensor back through ``send`` (data-parallel runs with global pairs)."""
         c = self.cfg
         enc, dec, dis = self.encoder, self.decoder, self.discriminator
         n_aux = aux_in.size(-1)
         spec_in += torch.randn_like(spec_in, requires_grad=False) * c["spec_noise"]
         styles = enc(spec_in)
         dec(styles)  # result unused by the reference too, but advances BN stats and the RNG
-        out = {}
         self.zerograd()
         loss = adversarial_loss(spec_in, styles, dis, alpha_, batch_size=c["batch_size"])
-        self._finish("adversarial", loss)
-        out["adversarial"] = loss
+        loss.backward()
+        yield "adversarial", loss
         self.zerograd()
         styles = enc(spec_in)
-        loss = kendall_constraint(aux_in, styles[:, :n_aux], activate=c["kendall_activation"])
-        self._finish("correlation", loss)
-        out["kendall"] = loss
+        if kendall is None:
+            loss = kendall_constraint(aux_in, styles[:, :n_aux], activate=c["kendall_activation"])
+        else:       # the caller forms the rank loss (it needs the styles of the other replicas) and sends it back
+            loss = yield "correlation_styles", (aux_in, styles[:, :n_aux])
+        loss.backward()
+        yield "correlation", loss
         self.zerograd()
         loss = recon_loss(spec_in, dec(enc(spec_in)), scale=c["use_flex_spec_target"])
-        self._finish("reconstruction", loss)
-        out["recon"] = loss
+        loss.backward()
+        yield "reconstruction", loss
         self.zerograd()
         styles = enc(spec_in)
         loss = mutual_info_loss(spec_in, styles, enc, dec)
-        self._finish("mutual_info", loss)
-        out["mutual_info"] = loss
+        loss.backward()
+        yield "mutual_info", loss
         if epoch < self.epoch_stop_smooth:
             self.zerograd()
             loss = smoothness_loss(dec(enc(spec_in)), self.gau_kernel_size)
-            self._finish("smoothness", loss)
-            out["smooth"] = loss
-        else:
-            out["smooth"] = torch.tensor(0)
+            loss.backward()
+            yield "smoothness", loss
         self.zerograd()
+
+    LOSS_KEY = {"adversarial": "adversarial", "correlation": "kendall", "reconstruction": "recon",
+                "mutual_info": "mutual_info", "smoothness": "smooth"}
+
+    # trainer.py:103-204 -- one batch through the five phases
+    def train_step(self, spec_in, aux_in, alpha_, epoch=0):
+        out = {"smooth": torch.tensor(0)}
+        for name, loss in self.step_phases(spec_in, aux_in, alpha_, epoch):
+            self._finish(name)
+            out[self.LOSS_KEY[name]] = loss
         self.last = {k: float(v.detach()) for k, v in out.items()}
         return self.last
 
@@ -301,6 +314,77 @@ class OracleTrainer:
                 callback(epoch, metrics)
         torch.autograd.set_detect_anomaly(prev_anomaly)
         return metrics
+
+
+# ----------------------------------------------------------------------------- data parallel emulation
+def train_step_sharded(replicas, shards, alpha_, rng_states, epoch=0, global_pairs=False, hook=None):
+    """Synchronous data parallelism over ``W = len(replicas)`` ranks, emulated sequentially ("parity
+    under DP"): ``replicas`` are ``OracleTrainer``s holding the SAME weights and optimizer state, ``shards[r] =
+    (spec, aux)`` is rank r's slice of the global batch, ``rng_states[r]`` the state of rank r's own generator
+    (updated in place).  Per phase every replica runs forward + backward on its shard -- per-replica BatchNorm batch
+    statistics and, by default, the rank loss over the pairs INSIDE the shard (DDP semantics) -- the parameter
+    gradients are averaged over the replicas, and every replica applies the averaged gradient (so the replicas stay
+    identical).  ``global_pairs``: the rank loss runs over all pairs of the global batch instead (what the
+    reference's single-process loss on that batch computes, functions.py:63-77); each replica differentiates the
+    global loss w.r.t. its own rows only and the contribution is scaled by W, so that the AVERAGE over replicas is
+    the gradient of the global loss.  ``hook(name, local_grads[r][i], mean_grads[i])`` sees every phase.
+    Returns the per-replica loss dictionaries."""
+    W = len(replicas)
+    outs = [{"smooth": 0.0} for _ in range(W)]
+
+    gens = []
+    for r, tr in enumerate(replicas):
+        torch.set_rng_state(rng_states[r])
+        gens.append(tr.step_phases(shards[r][0], shards[r][1], alpha_, epoch, kendall=True if global_pairs else None))
+        rng_states[r] = torch.get_rng_state()
+    n_phases = 5 if epoch < replicas[0].epoch_stop_smooth else 4
+    for ph in range(n_phases):
+        names, losses = [], []
+        pending = []
+        for r, g in enumerate(gens):
+            torch.set_rng_state(rng_states[r])
+            item = next(g)
+            rng_states[r] = torch.get_rng_state()
+            if item[0] == "correlation_styles":
+                pending.append(item[1])
+            else:
+                names.append(item[0])
+                losses.append(item[1])
+        if pending:
+            # every replica's phase-B styles exist now: rank r differentiates the GLOBAL loss w.r.t. its own rows
+            # (the other shards' rows enter as constants), scaled by W so that the average over ranks is the
+            # gradient of the global loss
+            all_aux = torch.cat([a_ for a_, _ in pending])
+            act = replicas[0].cfg["kendall_activation"]
+            for r, g in enumerate(gens):
+                parts = [z_ if q == r else z_.detach() for q, (_, z_) in enumerate(pending)]
+                loss = W * kendall_constraint(all_aux, torch.cat(parts), activate=act)
+                name, loss_back = g.send(loss)
+                names.append(name)
+                losses.append(loss_back / W)            # the loss every rank reports is the global one
+        assert len(set(names)) == 1
+        name = names[0]
+        plists = [[p for grp in tr.optimizers[name].param_groups for p in grp["params"]] for tr in replicas]
+        local = [[None if p.grad is None else p.grad.detach().clone() for p in pl] for pl in plists]
+        mean = []
+        for i in range(len(plists[0])):
+            gs = [local[r][i] for r in range(W)]
+            mean.append(None if gs[0] is None else torch.stack(gs).sum(0) / W)
+        for r in range(W):
+            for p, g_ in zip(plists[r], mean):
+                if g_ is not None:
+                    p.grad = g_.clone()
+        if hook is not None:
+            hook(name, local, mean)
+        for r, tr in enumerate(replicas):
+            tr._finish(name)
+            outs[r][OracleTrainer.LOSS_KEY[name]] = float(losses[r].detach())
+    for r, g in enumerate(gens):
+        torch.set_rng_state(rng_states[r])
+        for _ in g:
+            raise AssertionError("more phases than expected")
+        rng_states[r] = torch.get_rng_state()
+    return outs
 
 
 # ----------------------------------------------------------------------------- derived parity bounds

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librankaae_hip.so")
 
 RAAE_MAX_PARTS = 512
-ABI_VERSION = 9
+ABI_VERSION = 10
 IN_NONE, IN_PRELU_BN_DROP, IN_PRELU_DROP = 0, 1, 2
 OUT_RAW, OUT_STATS_PRELU, OUT_STATS_RAW, OUT_SOFTPLUS, OUT_RELU = 0, 1, 2, 3, 4
 G_DIRECT, G_SOFTPLUS, G_PRELU_BN, G_PRELU, G_RELU = 0, 1, 2, 3, 4
@@ -142,6 +142,8 @@ SIGNATURES = {
     "raae_style_bn_bwd": (_I, [_P, _P, _I, _I, _PB, _F, _P, _P]),
     "raae_rank_loss_work_bytes": (_L, [_I, _I]),
     "raae_rank_loss_fwd_bwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "raae_rank_rows_pairs": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "raae_rank_rows_finish": (_I, [_P, _I, _I, _I, _I, C.c_float, _P, _P, _P, _I, _P]),
     "raae_style_metrics": (_I, [_P, _I, _I, _P, _P, _P, _P]),
     "raae_group_mean": (_I, [_P, _I, _I, _I, _P, _P]),
     "raae_recon_loss_fwd_bwd": (_I, [_P, _P, _I, _I, _I, _P, _PI, _P, C.POINTER(LossFinT), _P]),

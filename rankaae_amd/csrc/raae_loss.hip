@@ -70,8 +70,15 @@ struct RankWork {   // per-workgroup partial: [k]{n_pos, n_neg} ints and {S_pos,
 // Thread = (row i, descriptor k, j-chunk c); R rows per thread (register blocking for large B).
 // The 8 chunk lanes of a (row, k) are adjacent lanes: their partial results meet through
 // wavefront shuffles (xor 1, 2, 4).  Workgroups grid-stride over row groups.
+// 2-D tiling for large batches: workgroup = (row-group slice ib, column block jb); block jb streams the columns
+// [jb * jchunk, (jb + 1) * jchunk) and leaves per-(row, k) partial g+- for that block, which the finalize adds in
+// block order (fixed order => deterministic; the counts are integers and exact either way).  At B = 4096 this is
+// 171 row groups x 6 column blocks = 1026 workgroups for the 256 CUs instead of 171.
+// Rows are [row0, row0 + nrows) of arrays with n_all rows, columns ALL n_all rows: nrows == n_all is the
+// reference's loss over one batch; nrows < n_all is one rank's share of the global pairs under data parallelism.
 template <int KA, int R>
-__global__ __launch_bounds__(256) void rank_pairs_kernel(const float* d, int ldd, const float* z, int ldz, int B,
+__global__ __launch_bounds__(256) void rank_pairs_kernel(const float* d, int ldd, const float* z, int ldz, int n_all,
+                                                         int row0, int nrows, int nj, int jchunk,
                                                          RankWork* part, float* gpos, float* gneg) {
     constexpr int IPB = 32 / KA;            // (row, k) slots per block = IPB * KA <= 32
     __shared__ float sd[RANK_TJ * KA], sz[RANK_TJ * KA];
@@ -83,29 +90,31 @@ __global__ __launch_bounds__(256) void rank_pairs_kernel(const float* d, int ldd
     double tsp = 0.0, tsn = 0.0;            // block totals of this (il, k) slot over all its row groups
     long long tnp = 0, tnn = 0;
     const int rows_per_group = IPB * R;
-    const int ngroups = (B + rows_per_group - 1) / rows_per_group;
-    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int ngroups = (nrows + rows_per_group - 1) / rows_per_group;
+    const int jb = blockIdx.x % nj, ib = blockIdx.x / nj, ni_wg = gridDim.x / nj;
+    const int jlo = jb * jchunk, jhi = min(n_all, jlo + jchunk);
+    for (int grp = ib; grp < ngroups; grp += ni_wg) {
         float di[R], zi[R], gp[R], gn[R], sp[R], sn[R];
         int np[R], nn[R], irow[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            irow[r] = grp * rows_per_group + r * IPB + il;
-            const bool ok = slot && irow[r] < B;
-            di[r] = ok ? d[(size_t)irow[r] * ldd + k] : 0.f;
-            zi[r] = ok ? z[(size_t)irow[r] * ldz + k] : 0.f;
+            irow[r] = grp * rows_per_group + r * IPB + il;           // local row index
+            const bool ok = slot && irow[r] < nrows;
+            di[r] = ok ? d[(size_t)(row0 + irow[r]) * ldd + k] : 0.f;
+            zi[r] = ok ? z[(size_t)(row0 + irow[r]) * ldz + k] : 0.f;
             gp[r] = gn[r] = sp[r] = sn[r] = 0.f; np[r] = nn[r] = 0;
         }
-        for (int j0 = 0; j0 < B; j0 += RANK_TJ) {
-            const int nj = min(RANK_TJ, B - j0);
+        for (int j0 = jlo; j0 < jhi; j0 += RANK_TJ) {
+            const int ntile = min(RANK_TJ, jhi - j0);
             __syncthreads();
-            for (int idx = tid; idx < nj * KA; idx += 256) {
+            for (int idx = tid; idx < ntile * KA; idx += 256) {
                 const int jj = idx / KA, kk = idx - jj * KA;
                 sd[idx] = d[(size_t)(j0 + jj) * ldd + kk];
                 sz[idx] = z[(size_t)(j0 + jj) * ldz + kk];
             }
             __syncthreads();
             if (slot) {
-                for (int jj = c; jj < nj; jj += RANK_JC) {
+                for (int jj = c; jj < ntile; jj += RANK_JC) {
                     const float dj = sd[jj * KA + k], zj = sz[jj * KA + k];
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
@@ -121,7 +130,7 @@ __global__ __launch_bounds__(256) void rank_pairs_kernel(const float* d, int ldd
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             // rows beyond B hold di = zi = 0 against real j rows: discard them
-            const bool ok = slot && irow[r] < B;
+            const bool ok = slot && irow[r] < nrows;
             float a = gp[r], b2 = gn[r];
             double e = (double)sp[r], f = (double)sn[r];
             int g = np[r], h = nn[r];
@@ -132,7 +141,7 @@ __global__ __launch_bounds__(256) void rank_pairs_kernel(const float* d, int ldd
                 g += __shfl_xor(g, o, 64); h += __shfl_xor(h, o, 64);
             }
             if (ok && c == 0) {
-                gpos[(size_t)irow[r] * KA + k] = a; gneg[(size_t)irow[r] * KA + k] = b2;
+                gpos[((size_t)jb * nrows + irow[r]) * KA + k] = a; gneg[((size_t)jb * nrows + irow[r]) * KA + k] = b2;
                 tsp += e; tsn += f; tnp += g; tnn += h;
             }
         }
@@ -154,7 +163,11 @@ __global__ __launch_bounds__(256) void rank_pairs_kernel(const float* d, int ldd
 
 // finalize: c_k, loss, dz[i][k] = -(2/norm)(c_k g+ + g-).  Every workgroup re-derives c_k from the
 // partials (16 slices per descriptor, fixed order), then grid-strides over dz.
-__global__ __launch_bounds__(256) void rank_finalize_kernel(const RankWork* part, int nparts, int B, int KA, int activate,
+// `totals` != NULL: the per-descriptor totals {n+, n-, S+, S-} [4][16] doubles are given (summed over the ranks of a
+// data-parallel run: global pairs) and `part` is not read.  norm = (n_all^2 - n_all) * KA; `scale` multiplies dz
+// (the number of ranks, whose gradients the engine AVERAGES).
+__global__ __launch_bounds__(256) void rank_finalize_kernel(const RankWork* part, int nparts, const double* totals, int n_all,
+                                                            int nrows, int nj, int KA, int activate, float scale,
                                                             const float* gpos, const float* gneg, float* loss,
                                                             float* dz, int ldz) {
     __shared__ float s_c[RANK_MAXK];
@@ -162,8 +175,8 @@ __global__ __launch_bounds__(256) void rank_finalize_kernel(const RankWork* part
     __shared__ double r_s[2][256];
     __shared__ long long r_n[2][256];
     const int tid = threadIdx.x;
-    const double norm = ((double)B * (double)B - (double)B) * (double)KA;
-    {
+    const double norm = ((double)n_all * (double)n_all - (double)n_all) * (double)KA;
+    if (totals == nullptr) {
         const int k = tid & 15, sl = tid >> 4;          // 16 slices
         long long np = 0, nn = 0; double sp = 0.0, sn = 0.0;
         if (k < KA)
@@ -176,9 +189,14 @@ __global__ __launch_bounds__(256) void rank_finalize_kernel(const RankWork* part
     __syncthreads();
     if (tid < KA) {
         long long np = 0, nn = 0; double sp = 0.0, sn = 0.0;
-        for (int sl = 0; sl < 16; ++sl) {
-            sp += r_s[0][sl * 16 + tid]; sn += r_s[1][sl * 16 + tid];
-            np += r_n[0][sl * 16 + tid]; nn += r_n[1][sl * 16 + tid];
+        if (totals == nullptr) {
+            for (int sl = 0; sl < 16; ++sl) {
+                sp += r_s[0][sl * 16 + tid]; sn += r_s[1][sl * 16 + tid];
+                np += r_n[0][sl * 16 + tid]; nn += r_n[1][sl * 16 + tid];
+            }
+        } else {
+            np = (long long)totals[tid]; nn = (long long)totals[16 + tid];      // exact: counts < 2^53
+            sp = totals[32 + tid]; sn = totals[48 + tid];
         }
         double c = 1.0;
         if (activate) {
@@ -195,12 +213,44 @@ __global__ __launch_bounds__(256) void rank_finalize_kernel(const RankWork* part
         loss[0] = (float)(-t / norm);
     }
     if (dz != nullptr) {
-        const float f = (float)(-2.0 / norm);
-        const long n = (long)B * ldz;
+        const float f = (float)(-2.0 / norm) * scale;
+        const long n = (long)nrows * ldz;
+        const size_t blk = (size_t)nrows * KA;
         for (long idx = (long)blockIdx.x * 256 + tid; idx < n; idx += (long)gridDim.x * 256) {
             const int i = (int)(idx / ldz), k = (int)(idx - (long)i * ldz);
-            dz[idx] = (k < KA) ? f * (s_c[k] * gpos[(size_t)i * KA + k] + gneg[(size_t)i * KA + k]) : 0.f;
+            float v = 0.f;
+            if (k < KA) {
+                float gp = 0.f, gn = 0.f;
+                for (int b = 0; b < nj; ++b) { gp += gpos[b * blk + (size_t)i * KA + k]; gn += gneg[b * blk + (size_t)i * KA + k]; }
+                v = f * (s_c[k] * gp + gn);
+            }
+            dz[idx] = v;
         }
+    }
+}
+
+// per-descriptor totals {n+, n-, S+, S-} of this rank's pairs as [4][16] doubles (fixed order): what a data-parallel
+// run all-reduces between the pair pass and the finalize
+__global__ __launch_bounds__(256) void rank_totals_kernel(const RankWork* part, int nparts, int KA, double* totals) {
+    __shared__ double r_s[2][256];
+    __shared__ long long r_n[2][256];
+    const int tid = threadIdx.x, k = tid & 15, sl = tid >> 4;
+    long long np = 0, nn = 0; double sp = 0.0, sn = 0.0;
+    if (k < KA)
+        for (int p = sl; p < nparts; p += 16) {
+            np += part[p].n_pos[k]; nn += part[p].n_neg[k];
+            sp += part[p].s_pos[k]; sn += part[p].s_neg[k];
+        }
+    r_s[0][tid] = sp; r_s[1][tid] = sn; r_n[0][tid] = np; r_n[1][tid] = nn;
+    __syncthreads();
+    if (tid < 16) {
+        np = 0; nn = 0; sp = 0.0; sn = 0.0;
+        if (tid < KA)
+            for (int s2 = 0; s2 < 16; ++s2) {
+                sp += r_s[0][s2 * 16 + tid]; sn += r_s[1][s2 * 16 + tid];
+                np += r_n[0][s2 * 16 + tid]; nn += r_n[1][s2 * 16 + tid];
+            }
+        totals[tid] = (double)np; totals[16 + tid] = (double)nn; totals[32 + tid] = sp; totals[48 + tid] = sn;
     }
 }
 
@@ -437,29 +487,43 @@ extern "C" int raae_style_bn_bwd(const float* dstyles, const float* styles, int 
     RAAE_LAUNCH_RET();
 }
 
-static int rank_grid(int B, int n_aux, int* R) {
+#define RANK_MAXWG 2048       // workgroups (= RankWork partials) of the pair pass
+#define RANK_MAXNJ 16         // column blocks
+struct RankGrid { int R, nwg, nj, jchunk; };
+static RankGrid rank_grid(int n_all, int nrows, int n_aux) {
+    RankGrid g;
     const int ipb = 32 / n_aux;
-    *R = B > 1024 ? 4 : 1;
-    long groups = (B + (long)ipb * *R - 1) / ((long)ipb * *R);
-    return (int)(groups < RAAE_MAX_PARTS ? groups : RAAE_MAX_PARTS);
+    g.R = nrows > 1024 ? 4 : 1;
+    const long groups = (nrows + (long)ipb * g.R - 1) / ((long)ipb * g.R);
+    // column blocks only where the pair pass is long enough to need them (>= 1024 workgroups for 256 CUs); the
+    // launch-bound small batches keep one block, i.e. one pass over the columns per row group
+    g.nj = 1;
+    if (n_all > 1024 && groups < 1024) {
+        g.nj = (int)((1024 + groups - 1) / groups);
+        if (g.nj > RANK_MAXNJ) g.nj = RANK_MAXNJ;
+        if (g.nj > n_all / RANK_TJ) g.nj = n_all / RANK_TJ;
+        if (g.nj < 1) g.nj = 1;
+    }
+    g.jchunk = ((n_all + g.nj - 1) / g.nj + RANK_TJ - 1) / RANK_TJ * RANK_TJ;
+    long ni = groups < RANK_MAXWG / g.nj ? groups : RANK_MAXWG / g.nj;
+    g.nwg = (int)ni * g.nj;
+    return g;
 }
+static size_t rank_part_bytes() { return ((size_t)RANK_MAXWG * sizeof(RankWork) + 255) & ~(size_t)255; }
 
 extern "C" long raae_rank_loss_work_bytes(int B, int n_aux) {
-    return (long)RAAE_MAX_PARTS * (long)sizeof(RankWork) + 2L * B * n_aux * (long)sizeof(float) + 256;
+    return (long)rank_part_bytes() + 2L * RANK_MAXNJ * B * n_aux * (long)sizeof(float) + 64 * (long)sizeof(double) + 256;
 }
 
-extern "C" int raae_rank_loss_fwd_bwd(const float* d, int ldd, const float* z, int ldz, int B, int n_aux, int activate,
-                                      void* work, float* loss, float* dz, void* stream) {
-    RAAE_CHECK_ARG(d && z && work && loss && B > 1 && n_aux >= 1 && n_aux <= RANK_MAXK && ldd >= n_aux && ldz >= n_aux);
-    int R = 1;
-    const int nb = rank_grid(B, n_aux, &R);
+static int rank_pairs_launch(const float* d, int ldd, const float* z, int ldz, int n_all, int row0, int nrows, int n_aux,
+                             void* work, RankGrid& g, float*& gpos, float*& gneg, hipStream_t st) {
+    g = rank_grid(n_all, nrows, n_aux);
     RankWork* part = (RankWork*)work;
-    float* gpos = (float*)((char*)work + (((size_t)RAAE_MAX_PARTS * sizeof(RankWork) + 255) & ~(size_t)255));
-    float* gneg = gpos + (size_t)B * n_aux;
-    hipStream_t st = (hipStream_t)stream;
+    gpos = (float*)((char*)work + rank_part_bytes());
+    gneg = gpos + (size_t)RANK_MAXNJ * nrows * n_aux;
 #define RANK_CASE(KA) case KA: \
-        if (R == 1) hipLaunchKernelGGL((rank_pairs_kernel<KA, 1>), dim3(nb), dim3(256), 0, st, d, ldd, z, ldz, B, part, gpos, gneg); \
-        else hipLaunchKernelGGL((rank_pairs_kernel<KA, 4>), dim3(nb), dim3(256), 0, st, d, ldd, z, ldz, B, part, gpos, gneg); \
+        if (g.R == 1) hipLaunchKernelGGL((rank_pairs_kernel<KA, 1>), dim3(g.nwg), dim3(256), 0, st, d, ldd, z, ldz, n_all, row0, nrows, g.nj, g.jchunk, part, gpos, gneg); \
+        else hipLaunchKernelGGL((rank_pairs_kernel<KA, 4>), dim3(g.nwg), dim3(256), 0, st, d, ldd, z, ldz, n_all, row0, nrows, g.nj, g.jchunk, part, gpos, gneg); \
         break;
     switch (n_aux) {
         RANK_CASE(1) RANK_CASE(2) RANK_CASE(3) RANK_CASE(4) RANK_CASE(5) RANK_CASE(6) RANK_CASE(7) RANK_CASE(8)
@@ -467,10 +531,49 @@ extern "C" int raae_rank_loss_fwd_bwd(const float* d, int ldd, const float* z, i
         default: return RAAE_EINVAL;
     }
 #undef RANK_CASE
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
+    return (int)hipGetLastError();
+}
+
+extern "C" int raae_rank_loss_fwd_bwd(const float* d, int ldd, const float* z, int ldz, int B, int n_aux, int activate,
+                                      void* work, float* loss, float* dz, void* stream) {
+    RAAE_CHECK_ARG(d && z && work && loss && B > 1 && n_aux >= 1 && n_aux <= RANK_MAXK && ldd >= n_aux && ldz >= n_aux);
+    hipStream_t st = (hipStream_t)stream;
+    RankGrid g;
+    float *gpos, *gneg;
+    const int rc = rank_pairs_launch(d, ldd, z, ldz, B, 0, B, n_aux, work, g, gpos, gneg, st);
+    if (rc) return rc;
     const int gf = dz ? grid_for((long)B * ldz, 256, 256) : 1;
-    hipLaunchKernelGGL(rank_finalize_kernel, dim3(gf), dim3(256), 0, st, part, nb, B, n_aux, activate, gpos, gneg, loss, dz, ldz);
+    hipLaunchKernelGGL(rank_finalize_kernel, dim3(gf), dim3(256), 0, st, (const RankWork*)work, g.nwg, (const double*)nullptr, B,
+                       B, g.nj, n_aux, activate, 1.f, gpos, gneg, loss, dz, ldz);
+    RAAE_LAUNCH_RET();
+}
+
+// One rank's share of the GLOBAL pairs of a data-parallel batch (rows [row0, row0 + nrows) against all n_all rows):
+// pair pass + this rank's totals; after the caller has summed `totals` over the ranks, raae_rank_rows_finish forms
+// the global loss and the gradient of this rank's rows.
+extern "C" int raae_rank_rows_pairs(const float* d_all, int ldd, const float* z_all, int ldz, int n_all, int row0, int nrows,
+                                    int n_aux, void* work, double* totals, void* stream) {
+    RAAE_CHECK_ARG(d_all && z_all && work && totals && n_all > 1 && nrows >= 1 && row0 >= 0 && row0 + nrows <= n_all &&
+                   n_aux >= 1 && n_aux <= RANK_MAXK && ldd >= n_aux && ldz >= n_aux);
+    hipStream_t st = (hipStream_t)stream;
+    RankGrid g;
+    float *gpos, *gneg;
+    const int rc = rank_pairs_launch(d_all, ldd, z_all, ldz, n_all, row0, nrows, n_aux, work, g, gpos, gneg, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(rank_totals_kernel, dim3(1), dim3(256), 0, st, (const RankWork*)work, g.nwg, n_aux, totals);
+    RAAE_LAUNCH_RET();
+}
+
+extern "C" int raae_rank_rows_finish(const double* totals, int n_all, int nrows, int n_aux, int activate, float scale,
+                                     void* work, float* loss, float* dz, int ldz, void* stream) {
+    RAAE_CHECK_ARG(totals && work && loss && n_all > 1 && nrows >= 1 && nrows <= n_all && n_aux >= 1 && n_aux <= RANK_MAXK &&
+                   (!dz || ldz >= n_aux));
+    const RankGrid g = rank_grid(n_all, nrows, n_aux);
+    float* gpos = (float*)((char*)work + rank_part_bytes());
+    float* gneg = gpos + (size_t)RANK_MAXNJ * nrows * n_aux;
+    const int gf = dz ? grid_for((long)nrows * ldz, 256, 256) : 1;
+    hipLaunchKernelGGL(rank_finalize_kernel, dim3(gf), dim3(256), 0, (hipStream_t)stream, (const RankWork*)nullptr, 0, totals,
+                       n_all, nrows, g.nj, n_aux, activate, scale, gpos, gneg, loss, dz, ldz);
     RAAE_LAUNCH_RET();
 }
 

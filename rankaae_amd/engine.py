@@ -458,6 +458,8 @@ class StepEngine:
                 from .rccl import GraphAllReduce, agree
                 ar = None
                 try:
+                    # (the constructor holds its own all-rank agreement before the collective communicator init:
+                    # either every rank goes on or every rank raises)
                     ar = GraphAllReduce(dist.get_rank(self.pg), dist.get_world_size(self.pg), device, self.pg)
                 except Exception:                                            # noqa: BLE001 -- fall back
                     ar = None
@@ -474,6 +476,9 @@ class StepEngine:
             raise ValueError(f"ae_form {cfg['ae_form']!r} is not reachable in the reference (SURVEY.md finding 4)")
         self.disc = DiscNet(discriminator, self)
         self.nstyle, self.n_aux = cfg["nstyle"], cfg["n_aux"]
+        # rank loss under data parallelism: "local" = pairs inside each rank's shard (DDP semantics, no exchange);
+        # "global" = all pairs of the global batch, i.e. the reference's loss on that batch (functions.py:63-77)
+        self.rank_pairs_global = self.world_size > 1 and str(cfg.get("rank_loss_pairs", "local")) == "global"
         self.L = cfg["dim_in"]
         self._make_optimizers()
         self.steps_dev = torch.zeros(8, dtype=torch.int32, device=device)
@@ -667,6 +672,10 @@ class StepEngine:
         P.m_dec.append(self.dec.mask_slots(tape, b))
         tape.finalize(dev)
         P.rank_work = torch.empty(ops.rank_loss_work_bytes(b, self.n_aux), dtype=torch.uint8, device=dev)
+        if self.rank_pairs_global:
+            P.aux_all = torch.empty(self.world_size * b, self.n_aux, device=dev)
+            P.z_all = torch.empty(self.world_size * b, ns, device=dev)
+            P.rank_totals = torch.zeros(64, dtype=torch.float64, device=dev)
         P.dstyles = torch.empty(b, ns, device=dev)
         P.dspec = torch.empty(b, self.L, device=dev)
         P.dout = torch.empty(b, self.L, device=dev)
@@ -714,35 +723,67 @@ class StepEngine:
         g.begin()
         self._capture["cur"] = g
 
-    def _all_reduce(self, buf):
-        """Mean over ranks on a dedicated communication stream.  RCCL's work events must never be recorded
-        on a stream that later captures a hipGraph: the process-group watchdog polls them with
-        hipEventQuery, which HIP rejects for an event last recorded on a capturing stream."""
+    def _run_comm(self, kind, bufs):
+        """One collective through ``torch.distributed`` on the dedicated communication stream.  RCCL's work events
+        must never be recorded on a stream that later captures a hipGraph: the process-group watchdog polls them
+        with hipEventQuery, which HIP rejects for an event last recorded on a capturing stream."""
+        import torch.distributed as dist
         from .parallel import allreduce_mean_
         cur = torch.cuda.current_stream()
         ev = torch.cuda.Event()
         ev.record(cur)
         self.comm_stream.wait_event(ev)
         with torch.cuda.stream(self.comm_stream):
-            allreduce_mean_(buf, self.pg)
+            if kind == "mean":
+                allreduce_mean_(bufs[0], self.pg)
+            elif kind == "sum":
+                dist.all_reduce(bufs[0], op=dist.ReduceOp.SUM, group=self.pg)
+            else:                                   # gather: dst[r*n:(r+1)*n] = src of rank r
+                src, dst = bufs
+                dist.all_gather(list(dst.view(self.world_size, -1).unbind(0)), src.reshape(-1), group=self.pg)
             ev2 = torch.cuda.Event()
             ev2.record(self.comm_stream)
         cur.wait_event(ev2)
 
-    def _collective(self, buf):
-        """Eager emission: run the all-reduce now.  Under capture: close the current graph segment,
-        remember the collective, open the next segment -- RCCL calls stay outside the hipGraphs."""
+    def _all_reduce(self, buf):
+        self._run_comm("mean", (buf,))
+
+    def _collective(self, buf, kind="mean", dst=None):
+        """``kind``: "mean" (gradient arenas), "sum" (float64 pair totals), "gather" (buf -> dst).  With the private
+        RCCL communicator the call is a node of the graph being captured (or an eager launch on this stream).
+        Otherwise -- eager emission: run it now through torch.distributed; under capture: close the current graph
+        segment, remember the collective, open the next segment (RCCL calls stay outside the hipGraphs)."""
+        bufs = (buf,) if dst is None else (buf, dst)
         if self.graph_ar is not None:
-            self.graph_ar.mean_(buf)           # a node of the graph being captured / an eager launch on this stream
+            {"mean": self.graph_ar.mean_, "sum": self.graph_ar.sum_, "gather": self.graph_ar.gather_}[kind](*bufs)
         elif self._capture is None:
-            self._all_reduce(buf)
+            self._run_comm(kind, bufs)
         else:
             g = self._capture["cur"]
             g.end()
-            self._capture["items"] += [g, buf]
+            self._capture["items"] += [g, lambda: self._run_comm(kind, bufs)]
             g = ops.Graph()
             g.begin()
             self._capture["cur"] = g
+
+    def _rank_loss(self, P, styles):
+        """Phase B's loss and d(loss)/d(styles).  Data parallel with ``rank_loss_pairs: global``: the ranks exchange
+        their [b, n_aux] descriptors and styles (all-gather), every rank pairs ITS rows with all W*b rows, the
+        per-descriptor pair counts and sums meet in one 512-byte all-reduce, and the row-local gradient is exact;
+        it is scaled by W because the parameter gradients are averaged over the ranks afterwards."""
+        c, b, ns, lo = self.cfg, P.b, self.nstyle, self.loss_out
+        if not self.rank_pairs_global:
+            ops.rank_loss_fwd_bwd(P.aux, self.n_aux, styles, ns, b, self.n_aux, c["kendall_activation"], P.rank_work,
+                                  lo[1:2], P.dstyles)
+            return
+        W = self.world_size
+        self._collective(P.aux, "gather", P.aux_all)
+        self._collective(styles, "gather", P.z_all)
+        ops.rank_rows_pairs(P.aux_all, self.n_aux, P.z_all, ns, W * b, self.rank * b, b, self.n_aux, P.rank_work,
+                            P.rank_totals)
+        self._collective(P.rank_totals, "sum")
+        ops.rank_rows_finish(P.rank_totals, W * b, b, self.n_aux, c["kendall_activation"], float(W), P.rank_work,
+                             lo[1:2], P.dstyles, ns)
 
     def _begin_phase(self, record):
         self._slab_notes = np.zeros(self.arena.n // 64, dtype=np.int16) if record else None
@@ -794,8 +835,7 @@ class StepEngine:
             styles, _ = enc.forward_pair(enc.forward_steps(E, P.spec, P.m_enc[1]), dec.forward_steps(D, styles, P.m_dec[0]))
         else:
             styles = enc.forward(E, P.spec, P.m_enc[1])
-        ops.rank_loss_fwd_bwd(P.aux, self.n_aux, styles, ns, b, self.n_aux, c["kendall_activation"], P.rank_work,
-                              lo[1:2], P.dstyles)
+        self._rank_loss(P, styles)
         enc.backward(E, P.spec, P.m_enc[1], P.dstyles)
         self._adam(P, "correlation", self._slab_notes)
         # ---- phase C: reconstruction (:164-172)
@@ -876,17 +916,15 @@ class StepEngine:
             for item in P.graphs[key]:
                 if isinstance(item, ops.Graph):
                     item.launch()
-                elif callable(item):
-                    item()
                 else:
-                    self._all_reduce(item)
+                    item()
             self._count_bn_step(smooth)
         else:
             self.emit_step(P, smooth, record=False)
 
     # -- roofline probe (bench.py): HIP-event timing of every kernel family the step launches
     @_on_stream
-    def roofline_probe(self, b, peak_gbs, reps=3, top=3):
+    def roofline_probe(self, b, peak_gbs, reps=3, top=3, detail=False):
         """``reps`` eager steps with ``ops.PROBE`` armed: every launch of the step is followed by ten identical
         launches replayed from a small hipGraph between two HIP events on the launching stream.  Returns the ``top``
         kernel families by share of the summed kernel time, each with its algorithmic bytes per launch (ops.block_bytes
@@ -896,7 +934,7 @@ class StepEngine:
         self.use_graph = False
         self.set_epoch(self.perm.clone(), float(self.alpha_dev))
         self.step(b, smooth=True)                  # plan + slab tables exist before the probe arms
-        ops.PROBE = ops.Probe(PROBE_REPS)
+        ops.PROBE = ops.Probe(PROBE_REPS, detail)
         try:
             for _ in range(reps):
                 self.step(b, smooth=True)

@@ -156,6 +156,17 @@ def rank_loss_fwd_bwd(d, ldd, z, ldz, B, n_aux, activate, work, loss, dz):
     _probed("rank_pairs_kernel", 4 * B * n_aux * 3, launch)      # O(B) bytes for B^2 n_aux pair operations: VALU-bound
 
 
+def rank_rows_pairs(d_all, ldd, z_all, ldz, n_all, row0, nrows, n_aux, work, totals):
+    check(_lib.load().raae_rank_rows_pairs(_ptr(d_all), ldd, _ptr(z_all), ldz, n_all, row0, nrows, n_aux, _ptr(work, None),
+                                           _ptr(totals, torch.float64), _stream()), "raae_rank_rows_pairs")
+
+
+def rank_rows_finish(totals, n_all, nrows, n_aux, activate, scale, work, loss, dz, ldz):
+    check(_lib.load().raae_rank_rows_finish(_ptr(totals, torch.float64), n_all, nrows, n_aux, 1 if activate else 0,
+                                            float(scale), _ptr(work, None), _ptr(loss), _ptr(dz), ldz, _stream()),
+          "raae_rank_rows_finish")
+
+
 def style_metrics(z, n, k, a_coef, work, out):
     check(_lib.load().raae_style_metrics(_ptr(z), n, k, _ptr(a_coef, torch.float64), _ptr(work, torch.float64),
                                          _ptr(out, torch.float64), _stream()), "raae_style_metrics")
@@ -293,8 +304,8 @@ class Probe:
     stream the kernel is launched on (a single bracketed eager launch would measure the host's submission latency,
     tens of microseconds, not the kernel).  ``records[family] = [(event0, event1, algorithmic bytes)]``."""
 
-    def __init__(self, reps=10):
-        self.reps, self.records, self.graphs, self.busy = reps, {}, [], False
+    def __init__(self, reps=10, detail=False):
+        self.reps, self.records, self.graphs, self.busy, self.detail = reps, {}, [], False, detail
 
     def summary(self):
         """``{family: dict(launches, avg_us, bytes)}`` -- call after a device synchronisation."""
@@ -309,11 +320,13 @@ class Probe:
 PROBE = None
 
 
-def _probed(family, nbytes, launch):
+def _probed(family, nbytes, launch, tag=None):
     out = launch()
     pr = PROBE
     if pr is None or pr.busy:
         return out
+    if pr.detail and tag is not None:
+        family = f"{family}[{tag}]"
     pr.busy = True
     try:
         g = Graph()
@@ -330,6 +343,10 @@ def _probed(family, nbytes, launch):
     finally:
         pr.busy = False
     return out
+
+
+def _ktag(k):
+    return f"{k.Cin}x{k.Lin}->{k.Cout}x{k.Lout}"
 
 
 def block_bytes(kernel, k, B, mask=False, need_dx=True, input_bn=True):
@@ -498,6 +515,7 @@ def block_fwd_a_args(view_in, mask, B, k, m, T1, Sh, E1, E2, pT1, pE2):
     a.wf2, a.bf2, a.se2 = _p(m.fc2.weight), _p(m.fc2.bias), _p(m.relu_excit_2.weight)
     a.T1, a.Sh, a.E1, a.E2, a.pT1, a.pE2 = _p(T1), _p(Sh), _p(E1), _p(E2), _p(pT1), _p(pE2)
     a.nbytes = block_bytes("fwd_a", k, B, mask=mask is not None)
+    a.tag = _ktag(k)
     return a
 
 
@@ -507,7 +525,7 @@ def block_fwd_a(a):
         n = C.c_int(0)
         check(_lib.load().raae_block_fwd_a(C.byref(a), C.byref(n), _stream()), "raae_block_fwd_a")
         return n.value
-    return _probed("block_fwd_a_kernel", a.nbytes, launch)
+    return _probed("block_fwd_a_kernel", a.nbytes, launch, a.tag)
 
 
 def block_fwd_pair(kind, x, y):
@@ -537,6 +555,7 @@ def block_fwd_b_args(vT1, vE2, vR, B, k, m, Sh, T2, E3, Y, pY):
     a.w2, a.b2, a.slope2 = _p(m.conv2.weight), _p(m.conv2.bias), _p(m.relu2.weight)
     a.T2, a.E3, a.Y, a.pY = _p(T2), _p(E3), _p(Y), _p(pY)
     a.nbytes = block_bytes("fwd_b", k, B)
+    a.tag = _ktag(k)
     return a
 
 
@@ -545,7 +564,7 @@ def block_fwd_b(a):
         n = C.c_int(0)
         check(_lib.load().raae_block_fwd_b(C.byref(a), C.byref(n), _stream()), "raae_block_fwd_b")
         return n.value
-    return _probed("block_fwd_b_kernel", a.nbytes, launch)
+    return _probed("block_fwd_b_kernel", a.nbytes, launch, a.tag)
 
 
 def block_bwd_b(gy, vT1, vE2, B, k, m, w, slab_stride, gslab, wgrad=None):
@@ -579,13 +598,13 @@ def block_bwd_b(gy, vT1, vE2, B, k, m, w, slab_stride, gslab, wgrad=None):
             check(_lib.load().raae_block_bwd_b_wgrad(C.byref(a), C.byref(wgrad), C.byref(n), ns, _stream()),
                   "raae_block_bwd_b_wgrad")
             return n.value, list(ns)[:wgrad.n_conv + wgrad.n_lin]
-        return _probed("block_bwd_b_wgrad_kernel", nbytes + wgrad.nbytes, launch2)
+        return _probed("block_bwd_b_wgrad_kernel", nbytes + wgrad.nbytes, launch2, _ktag(k))
 
     def launch():
         n = C.c_int(0)
         check(_lib.load().raae_block_bwd_b(C.byref(a), C.byref(n), _stream()), "raae_block_bwd_b")
         return n.value
-    return _probed("block_bwd_b_kernel", nbytes, launch)
+    return _probed("block_bwd_b_kernel", nbytes, launch, _ktag(k))
 
 
 def block_bwd_a(g1, ge, view_in, mask, B, k, m, w, dE2, dR, pdR, slab_stride, gslab):
@@ -614,7 +633,7 @@ def block_bwd_a(g1, ge, view_in, mask, B, k, m, w, dE2, dR, pdR, slab_stride, gs
         check(_lib.load().raae_block_bwd_a(C.byref(a), C.byref(n), _stream()), "raae_block_bwd_a")
         return n.value
     return _probed("block_bwd_a_kernel", block_bytes("bwd_a", k, B, mask=mask is not None, need_dx=dR is not None,
-                                                     input_bn=pdR is not None), launch)
+                                                     input_bn=pdR is not None), launch, _ktag(k))
 
 
 def block_wgrad_args(B, conv_tasks, lin_tasks, slab_stride):
@@ -632,6 +651,9 @@ def block_wgrad_args(B, conv_tasks, lin_tasks, slab_stride):
     a.nbytes = sum(4 * B * (cv.Cin * cv.Lin + cv.Cout * cv.Lout) + 4 * (cv.Cout * (cv.Cin // cv.groups) * cv.K + cv.Cout)
                    for _, cv, _, _, _ in conv_tasks) + \
         sum(4 * B * Cc * (E + Lin) + 4 * (E * Lin + E) for _, Cc, E, Lin, _, _, _ in lin_tasks)
+    if conv_tasks:
+        cv = conv_tasks[0][1]
+        a.tag = f"{len(conv_tasks)}conv+{len(lin_tasks)}lin {cv.Cin}x{cv.Lin}->{cv.Cout}x{cv.Lout}"
     return a
 
 
@@ -644,4 +666,4 @@ def block_wgrad(B, conv_tasks, lin_tasks, slab_stride, args=None):
         ns = (C.c_int * 6)()
         check(_lib.load().raae_block_wgrad(C.byref(a), ns, _stream()), "raae_block_wgrad")
         return list(ns)[:a.n_conv + a.n_lin]
-    return _probed("wgrad_multi_kernel", a.nbytes, launch)
+    return _probed("wgrad_multi_kernel", a.nbytes, launch, getattr(a, "tag", None))

@@ -13,7 +13,7 @@ import os
 import torch
 import torch.distributed as dist
 
-NCCL_FLOAT32, NCCL_SUM, NCCL_AVG = 7, 0, 4
+NCCL_FLOAT32, NCCL_FLOAT64, NCCL_SUM, NCCL_AVG = 7, 8, 0, 4
 
 
 class _UniqueId(C.Structure):
@@ -26,10 +26,11 @@ def _load():
     lib.ncclGetUniqueId.argtypes = [C.POINTER(_UniqueId)]
     lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
     lib.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
     lib.ncclCommDestroy.argtypes = [C.c_void_p]
     lib.ncclGetErrorString.restype = C.c_char_p
     lib.ncclGetErrorString.argtypes = [C.c_int]
-    for f in (lib.ncclGetUniqueId, lib.ncclCommInitRank, lib.ncclAllReduce, lib.ncclCommDestroy):
+    for f in (lib.ncclGetUniqueId, lib.ncclCommInitRank, lib.ncclAllReduce, lib.ncclAllGather, lib.ncclCommDestroy):
         f.restype = C.c_int
     return lib
 
@@ -49,15 +50,26 @@ class GraphAllReduce:
 
     def __init__(self, rank, world, device, group=None):
         self.rank, self.world, self.device, self.group = rank, world, device, group
-        self.lib = _load()
-        uid = _UniqueId()
-        if rank == 0:
-            self._check(self.lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
-        box = [C.string_at(C.byref(uid), 128) if rank == 0 else None]
+        # every step of the bootstrap is followed by an agreement of ALL ranks (one MIN all-reduce on the torch
+        # process group), so that a rank that failed never leaves the others inside a collective it skipped: rank 0
+        # always enters the unique-id broadcast (with a zero id when it could not make one), and the communicator
+        # is only initialised -- collectively, it blocks until every rank has joined -- once every rank has the
+        # library loaded and a valid id
+        self.lib, uid, ok = None, _UniqueId(), True
+        try:
+            self.lib = _load()
+            if rank == 0:
+                self._check(self.lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        except Exception:                                     # noqa: BLE001
+            ok = False
+        box = [(C.string_at(C.byref(uid), 128) if ok else bytes(128)) if rank == 0 else None]
         if world > 1:
             dist.broadcast_object_list(box, src=0, group=group)
-        C.memmove(C.byref(uid), box[0], 128)
+        ok = ok and any(box[0])
         self.comm = C.c_void_p()
+        if not agree(ok, device, group):
+            raise RuntimeError("RCCL bootstrap failed on at least one rank")
+        C.memmove(C.byref(uid), box[0], 128)
         with torch.cuda.device(device):
             self._check(self.lib.ncclCommInitRank(C.byref(self.comm), world, uid, rank), "ncclCommInitRank")
 
@@ -71,6 +83,23 @@ class GraphAllReduce:
         self._check(self.lib.ncclAllReduce(C.c_void_p(buf.data_ptr()), C.c_void_p(buf.data_ptr()), buf.numel(),
                                            NCCL_FLOAT32, NCCL_AVG, self.comm, C.c_void_p(stream)), "ncclAllReduce")
         return buf
+
+    def sum_(self, buf):
+        """In-place SUM of a float64 device buffer (the rank loss's pair totals under global pairs)."""
+        assert buf.dtype == torch.float64 and buf.is_contiguous() and buf.device == self.device
+        stream = torch.cuda.current_stream().cuda_stream
+        self._check(self.lib.ncclAllReduce(C.c_void_p(buf.data_ptr()), C.c_void_p(buf.data_ptr()), buf.numel(),
+                                           NCCL_FLOAT64, NCCL_SUM, self.comm, C.c_void_p(stream)), "ncclAllReduce")
+        return buf
+
+    def gather_(self, src, dst):
+        """``dst[r * n : (r + 1) * n] = src`` of rank r (fp32, n = src.numel())."""
+        assert src.dtype == dst.dtype == torch.float32 and src.is_contiguous() and dst.is_contiguous()
+        assert dst.numel() == self.world * src.numel()
+        stream = torch.cuda.current_stream().cuda_stream
+        self._check(self.lib.ncclAllGather(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), src.numel(),
+                                           NCCL_FLOAT32, self.comm, C.c_void_p(stream)), "ncclAllGather")
+        return dst
 
     def self_test(self):
         """Known-answer test, eager and captured; returns True only when every rank passed."""

@@ -57,3 +57,200 @@ def test_dp_path_one_rank_equals_plain(case, in_graph):
     dist.destroy_process_group()
     assert torch.equal(results[0][0], results[1][0])
     assert results[0][1] == results[1][1]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Two REAL ranks (two processes) on the one GPU over gloo: the N > 1 path end to end -- broadcast of the weights,
+# sharded gather, per-replica BatchNorm, the rank loss over local or global pairs, the per-phase gradient mean and
+# Adam on it -- against the sharded CPU emulation (oracle.ref_train.train_step_sharded, SURVEY 8e "parity under DP").
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _two_rank_worker(rank, world, port, case, pairs, use_graph):
+    import numpy as np
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import test_engine_gpu as T
+    from oracle import ref_train
+    from rankaae_amd import model as pm
+    from rankaae_amd.engine import StepEngine
+    torch.set_num_threads(1)
+    g, cfg, spec, aux = T.load_case(case)
+    cfg = dict(cfg, rank_loss_pairs=pairs, pair_unused_forwards=False)
+    b = cfg["batch_size"] // world                 # the fixture's batch is the GLOBAL batch here
+    cfg["batch_size"] = b                          # z_real of the adversarial phase has the configured (per-rank) size
+    seed = g["model_seed"]
+    # -- the emulation: `world` replicas with identical weights, each with its own generator state
+    replicas = []
+    for _ in range(world):
+        torch.manual_seed(seed)
+        tr = ref_train.OracleTrainer(spec, aux, cfg)
+        for m in (tr.encoder, tr.decoder, tr.discriminator):
+            m.train()
+        replicas.append(tr)
+    n_train = len(replicas[0].train_spec)
+    perm = torch.randperm(n_train, generator=torch.Generator().manual_seed(11))
+    rows = [perm[r * b:(r + 1) * b].numpy() for r in range(world)]
+    shards = [(torch.tensor(replicas[0].train_spec[rw], dtype=torch.float32),
+               torch.tensor(replicas[0].train_aux[rw], dtype=torch.float32)) for rw in rows]
+    states = []
+    for r in range(world):
+        torch.manual_seed(1000 + r)
+        states.append(torch.get_rng_state())
+    alpha_ = ref_train.alpha(0.3, cfg["alpha_flat_step"], cfg["alpha_limit"])
+    o_local, o_mean = {}, {}
+
+    def o_hook(name, local, mean):
+        o_local[name], o_mean[name] = local[rank], mean
+    # teacher forcing at phase granularity, as in P2 (tests/test_engine_gpu.py): this rank's replica after every
+    # optimizer step
+    o_post = {}
+    mine_o = replicas[rank]
+    mine_o.post_hook = lambda name: o_post.__setitem__(name, T._snapshot(mine_o, name))
+    smooth = 0 < cfg.get("epoch_stop_smooth", 500)
+    want = ref_train.train_step_sharded(replicas, shards, alpha_, states, epoch=0 if smooth else 10 ** 9,
+                                        global_pairs=pairs == "global", hook=o_hook)[rank]
+    # -- the engine, rank `rank` of `world`
+    torch.manual_seed(seed)
+    cls = pm.AE_CLS_DICT[cfg["ae_form"]]
+    enc = cls["encoder"](nstyle=cfg["nstyle"], dropout_rate=cfg["dropout_rate"], dim_in=cfg["dim_in"], n_layers=cfg["n_layers"])
+    dec = cls["decoder"](nstyle=cfg["nstyle"], dropout_rate=cfg["dropout_rate"], last_layer_activation=cfg["decoder_activation"],
+                         dim_out=cfg["dim_out"], n_layers=cfg["n_layers"])
+    dis = pm.DiscriminatorFC(nstyle=cfg["nstyle"], dropout_rate=cfg["dis_dropout_rate"], noise=cfg["dis_noise"],
+                             layers=cfg["FC_discriminator_layers"])
+    eng = StepEngine(enc, dec, dis, cfg, T.DEV, rng_mode="host", use_graph=use_graph, world_size=world, rank=rank)
+    eng.set_data(spec[:n_train], aux[:n_train])
+    members = {"adversarial": ("disc", "enc"), "correlation": ("enc",), "reconstruction": ("enc", "dec"),
+               "mutual_info": ("enc", "dec"), "smoothness": ("dec",)}
+    mine = {"disc": list(eng.dis_mod.parameters()), "enc": list(eng.enc_mod.parameters()), "dec": list(eng.dec_mod.parameters())}
+    e_params = {n: [p for grp in mem for p in mine[grp]] for n, mem in members.items()}
+    theirs = {"disc": list(mine_o.discriminator.parameters()), "enc": list(mine_o.encoder.parameters()),
+              "dec": list(mine_o.decoder.parameters())}
+    o_params = {n: [p for grp in mem for p in theirs[grp]] for n, mem in members.items()}
+    e_local, e_mean = {}, {}
+    eng.phase_hook = lambda name, P: e_local.__setitem__(name, eng.phase_gradient(P, name).cpu())
+
+    def after(name, P):
+        e_mean[name] = eng.G_flat[eng.opts[name].lo:eng.opts[name].hi].cpu().clone()
+        snap = o_post[name]                         # engine <- this rank's replica right after its optimizer step
+        eng.enc_mod.load_state_dict(snap["enc"])
+        eng.dec_mod.load_state_dict(snap["dec"])
+        eng.dis_mod.load_state_dict(snap["dis"])
+        o = eng.opts[name]
+        for p_e, p_o in zip(e_params[name], o_params[name]):
+            st = snap["opt"][id(p_o)]
+            off = eng.arena.off(p_e) - o.lo
+            o.m[off:off + p_e.numel()].copy_(st["exp_avg"].reshape(-1))
+            o.v[off:off + p_e.numel()].copy_(st["exp_avg_sq"].reshape(-1))
+    eng.post_phase_hook = after
+    init = eng.arena.P.clone()
+    reps = 3 if use_graph else 1                   # graph mode: eager emission, capture, and the compared REPLAY
+    for rep in range(reps):
+        eng.arena.P.copy_(init)
+        for o in eng.opts.values():
+            o.m.zero_(); o.v.zero_()
+        eng.steps_dev.zero_()
+        torch.manual_seed(1000 + rank)
+        eng.set_epoch(perm, alpha_, start=rank * b, stride=world * b)
+        eng.step(b, smooth=smooth)
+    torch.cuda.synchronize()
+    got = eng.losses()
+    bad = []
+    for key, name in (("adversarial", "adversarial"), ("kendall", "correlation"), ("recon", "reconstruction"),
+                      ("mutual_info", "mutual_info"), ("smooth", "smoothness")):
+        if key == "smooth" and not smooth:
+            continue
+        # rank loss: a pair whose style difference is rounding residue may be counted on the other side (pair COUNTS
+        # weigh the concordant pairs, functions.py:73-75): 32-row shards have ~500 pairs per descriptor
+        tol_abs = 1e-4 * abs(want[key]) + 1e-6
+        if key == "kendall":       # up to three such pairs, each worth 4 / (n^2 - n) of c_k (see test_p4_* for the bound)
+            n_pairs_rows = world * b if pairs == "global" else b
+            tol_abs += 3 * 0.25 * 4.0 / (n_pairs_rows * n_pairs_rows - n_pairs_rows)
+        if abs(got[key] - want[key]) > tol_abs:
+            bad.append(f"rank {rank} loss {key}: hip {got[key]!r} emulation {want[key]!r}")
+    for name in members:
+        if name == "smoothness" and not smooth:
+            continue
+        lo = eng.opts[name].lo
+        for which, e_flat, o_list in (("local", e_local[name], o_local[name]), ("mean", e_mean[name], o_mean[name])):
+            phase_max = max([float(t.abs().max()) for t in o_list if t is not None] + [0.0])
+            for p_e, g_o in zip(e_params[name], o_list):
+                off = eng.arena.off(p_e) - lo
+                mine_g = e_flat[off:off + p_e.numel()].view(p_e.shape).double()
+                ref_g = torch.zeros_like(mine_g) if g_o is None else g_o.double()
+                err, scale = float((mine_g - ref_g).abs().max()), float(ref_g.abs().max())
+                # 5e-3 |g|inf as in P2; a flipped pair count moves every rank-loss gradient (2e-2); the conv networks'
+                # BatchNorms over 32-row shards amplify fp32 rounding twice as much as P2's 64-row batches (1e-2)
+                tol = 2e-2 if name == "correlation" else (1e-2 if cfg["ae_form"] == "compact" else 5e-3)
+                if err > tol * scale + 1e-5 * phase_max + 1e-7:
+                    bad.append(f"rank {rank} {name} {which} gradient: err {err:.3e} |g|inf {scale:.3e}")
+    if use_graph:
+        items = eng.plans[b].graphs[bool(smooth)]
+        assert items is not None and sum(1 for it in items if hasattr(it, "launch")) >= 5
+    dist.barrier()
+    dist.destroy_process_group()
+    assert not bad, "\n".join(bad[:20])
+
+
+@pytest.mark.parametrize("case,pairs,use_graph", [("fc_small", "local", False), ("compact_small", "local", True),
+                                                  ("fc_small", "global", True), ("compact_small", "global", False)])
+def test_two_ranks_match_sharded_oracle(case, pairs, use_graph):
+    import torch.multiprocessing as mp
+    mp.spawn(_two_rank_worker, args=(2, _free_port(), case, pairs, use_graph), nprocs=2, join=True)
+
+
+def _trainer_dp_worker(rank, world, port, work_dir, case):
+    import json
+    import numpy as np
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", RANKAAE_DP_BACKEND="gloo")
+    import torch.distributed as dist
+    import test_engine_gpu as T
+    from rankaae_amd.parameter import Parameters
+    from rankaae_amd.trainer import Trainer
+    g, cfg, spec, aux = T.load_case(case)
+    cfg = dict(cfg, max_epoch=3, batch_size=32, seed=5)
+    torch.manual_seed(g["model_seed"] + rank)          # ranks start from DIFFERENT weights: rank 0's must win
+    lines = []
+
+    class Log:
+        def info(self, msg):
+            lines.append(msg)
+    tr = Trainer.from_data(None, igpu=0, verbose=False, work_dir=work_dir, config_parameters=Parameters(cfg),
+                           logger=Log(), loss_logger=Log(), arrays=(spec, aux))
+    assert tr.world == world and tr.rank == rank and tr.engine.world_size == world
+    seen = []
+    metrics = tr.train(callback=lambda ep, m: seen.append(list(m)))
+    torch.cuda.synchronize()
+    # every rank ends with the same weights, the same metrics and the same learning rates
+    flat = tr.engine.arena.P.detach().cpu()
+    box = [None] * world
+    dist.all_gather_object(box, (flat, seen, [o.lr for o in tr.optimizers.values()]))
+    for other in box[1:]:
+        assert torch.equal(box[0][0], other[0]), "ranks diverged"
+        assert box[0][1] == other[1] and box[0][2] == other[2]
+    assert len(seen) == 3 and all(np.isfinite(metrics))
+    # only rank 0 writes: one header + one row (epoch 0) in its loss log, final.pt once
+    if rank == 0:
+        assert lines and lines[0].startswith("Epoch,Train_D") and lines[1].startswith("0,\t")
+        assert os.path.exists(os.path.join(work_dir, "final.pt"))
+    else:
+        assert not lines
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trainer_data_parallel_two_ranks(tmp_path):
+    """``Trainer.from_data(...).train()`` under WORLD_SIZE = 2 (what ``torch.distributed.run -m
+    rankaae_amd.cmd.train_sc`` starts): the ranks train ONE model data-parallel -- same permutation, disjoint
+    shards incl. the split tail, gradient mean per phase, metrics and schedules in lockstep -- and only rank 0
+    writes the log rows and ``final.pt``."""
+    import torch.multiprocessing as mp
+    mp.spawn(_trainer_dp_worker, args=(2, _free_port(), str(tmp_path), "compact_small"), nprocs=2, join=True)
+    model = torch.load(os.path.join(str(tmp_path), "final.pt"), map_location="cpu", weights_only=False)
+    assert set(model) == {"Encoder", "Decoder", "Style Discriminator"}

@@ -272,3 +272,21 @@ def test_exported_modules_forward_is_the_reference_forward(case):
     assert np.allclose(st, g["val_styles_first8"], rtol=1e-5, atol=1e-5), np.abs(st - np.array(g["val_styles_first8"])).max()
     for key, want in g["final_bn_buffers"]["Encoder"].items():
         assert np.allclose(enc.state_dict()[key].double().numpy(), want, rtol=1e-5, atol=1e-6), key
+
+
+def test_data_parallel_epoch_schedule_covers_the_permutation():
+    """``parallel.epoch_schedule``: full global batches then the tail split evenly over the ranks; the ranks' row
+    ranges are disjoint, in order, and leave at most world - 1 rows unused; world = 1 is the reference's loader
+    (every batch, the ragged last one included)."""
+    from rankaae_amd.parallel import epoch_schedule
+    assert epoch_schedule(489, 1, 64) == [(64, 64 * i, 64) for i in range(7)] + [(41, 448, 41)]
+    assert epoch_schedule(128, 1, 64) == [(64, 0, 64), (64, 64, 64)]
+    for n, w, b in ((489, 2, 32), (4900, 8, 256), (4900, 4, 256), (70, 2, 64), (10, 4, 64), (9, 8, 64)):
+        sched = epoch_schedule(n, w, b)
+        used = []
+        for rows, off, glob in sched:
+            assert glob == w * rows and rows >= 2
+            for r in range(w):
+                used += list(range(off + r * rows, off + (r + 1) * rows))
+        assert used == list(range(len(used))) and len(used) <= n and n - len(used) < max(w, 2 * w if not sched else w)
+    assert epoch_schedule(9, 8, 64) == []          # one row per rank: training-mode BatchNorm needs two
