@@ -22,6 +22,7 @@ namespace {
 using raae::prelu;
 
 #define CV_MAXC 64
+#define RAAE_BIG_ROWS 1024     // batches from here up run the BIG kernel instances (16-byte staging / elementwise paths)
 
 struct ViewStats { float mean[CV_MAXC]; float rstd[CV_MAXC]; };
 struct GradStats { float mean[CV_MAXC]; float rstd[CV_MAXC]; float m1[CV_MAXC]; float m2[CV_MAXC]; };
@@ -536,7 +537,9 @@ extern "C" int raae_conv_fwd(const raae_view_t* in, int B, const raae_conv_t* cv
         const int grid = t.ngroups < RAAE_MAX_PARTS ? t.ngroups : RAAE_MAX_PARTS;
         t.a.nsl = grid;
         if (out_nparts) *out_nparts = grid;
-        hipLaunchKernelGGL(conv_fwd_tiled_kernel, dim3(grid), dim3(256), sizeof(float) * t.S * per_in,
+        if (B >= RAAE_BIG_ROWS) hipLaunchKernelGGL(conv_fwd_tiled_kernel<true>, dim3(grid), dim3(256), sizeof(float) * t.S * per_in,
+                           (hipStream_t)stream, t);
+        else hipLaunchKernelGGL(conv_fwd_tiled_kernel<false>, dim3(grid), dim3(256), sizeof(float) * t.S * per_in,
                            (hipStream_t)stream, t);
         RAAE_LAUNCH_RET();
     }
@@ -563,7 +566,9 @@ extern "C" int raae_conv_bwd_data(const raae_grad_t* go, int B, const raae_conv_
         const int grid = t.ngroups < RAAE_MAX_PARTS ? t.ngroups : RAAE_MAX_PARTS;
         t.a.nsl = grid;
         if (din_nparts) *din_nparts = grid;
-        hipLaunchKernelGGL(conv_bwd_data_tiled_kernel, dim3(grid), dim3(256), sizeof(float) * t.S * per_g,
+        if (B >= RAAE_BIG_ROWS) hipLaunchKernelGGL(conv_bwd_data_tiled_kernel<true>, dim3(grid), dim3(256), sizeof(float) * t.S * per_g,
+                           (hipStream_t)stream, t);
+        else hipLaunchKernelGGL(conv_bwd_data_tiled_kernel<false>, dim3(grid), dim3(256), sizeof(float) * t.S * per_g,
                            (hipStream_t)stream, t);
         RAAE_LAUNCH_RET();
     }
@@ -593,7 +598,9 @@ extern "C" int raae_conv_bwd_weight(const raae_grad_t* go, int B, const raae_con
         { const int scap = (B + 127) / 128; if (t.S > scap) { t.S = scap; t.ngroups = (B + t.S - 1) / t.S; } }
         const int grid = t.ngroups < 128 ? t.ngroups : 128;
         if (nslab) *nslab = grid;
-        hipLaunchKernelGGL(conv_bwd_weight_tiled_kernel, dim3(grid), dim3(256), sizeof(float) * t.S * per,
+        if (B >= RAAE_BIG_ROWS) hipLaunchKernelGGL(conv_bwd_weight_tiled_kernel<true>, dim3(grid), dim3(256), sizeof(float) * t.S * per,
+                           (hipStream_t)stream, t);
+        else hipLaunchKernelGGL(conv_bwd_weight_tiled_kernel<false>, dim3(grid), dim3(256), sizeof(float) * t.S * per,
                            (hipStream_t)stream, t);
         RAAE_LAUNCH_RET();
     }
@@ -620,7 +627,7 @@ extern "C" int raae_lenlin_fwd(const raae_view_t* in, int B, int C, int Lin, con
         const int grid = t.ngroups < RAAE_MAX_PARTS ? t.ngroups : RAAE_MAX_PARTS;
         t.a.nsl = grid;
         if (out_nparts) *out_nparts = grid;
-        hipLaunchKernelGGL(lenlin_fwd_tiled_kernel, dim3(grid), dim3(256), sizeof(float) * (t.S * per + wfl),
+        hipLaunchKernelGGL(lenlin_fwd_tiled_kernel<false>, dim3(grid), dim3(256), sizeof(float) * (t.S * per + wfl),
                            (hipStream_t)stream, t);
         RAAE_LAUNCH_RET();
     }
@@ -647,7 +654,7 @@ extern "C" int raae_lenlin_bwd_data(const raae_grad_t* go, int B, int C, int E, 
         const int grid = t.ngroups < RAAE_MAX_PARTS ? t.ngroups : RAAE_MAX_PARTS;
         t.a.nsl = grid;
         if (din_nparts) *din_nparts = grid;
-        hipLaunchKernelGGL(lenlin_bwd_data_tiled_kernel, dim3(grid), dim3(256), sizeof(float) * (t.S * per + wfl),
+        hipLaunchKernelGGL(lenlin_bwd_data_tiled_kernel<false>, dim3(grid), dim3(256), sizeof(float) * (t.S * per + wfl),
                            (hipStream_t)stream, t);
         RAAE_LAUNCH_RET();
     }
@@ -672,7 +679,7 @@ extern "C" int raae_lenlin_bwd_weight(const raae_grad_t* go, int B, int C, int E
         t.ngroups = (B + t.S - 1) / t.S;
         const int grid = t.ngroups < 64 ? t.ngroups : 64;
         if (nslab) *nslab = grid;
-        hipLaunchKernelGGL(lenlin_bwd_weight_tiled_kernel, dim3(grid), dim3(256), sizeof(float) * t.S * per,
+        hipLaunchKernelGGL(lenlin_bwd_weight_tiled_kernel<false>, dim3(grid), dim3(256), sizeof(float) * t.S * per,
                            (hipStream_t)stream, t);
         RAAE_LAUNCH_RET();
     }
@@ -708,6 +715,13 @@ extern "C" int raae_grad_materialize(const raae_grad_t* go, int B, int C, int L,
 }
 
 // ---- shape-specialised instances of the fused block kernels (raae_block_shapes.inc)
+// (`big`: the instance for batches of >= 1024 rows, which carries the 16-byte staging / elementwise paths)
+#define RAAE_LAUNCH_KIND_BIG(KERNEL, ...) if (big) switch (kind) { \
+        case 0: hipLaunchKernelGGL((KERNEL<0, true>), __VA_ARGS__); break; case 1: hipLaunchKernelGGL((KERNEL<1, true>), __VA_ARGS__); break; \
+        case 2: hipLaunchKernelGGL((KERNEL<2, true>), __VA_ARGS__); break; case 3: hipLaunchKernelGGL((KERNEL<3, true>), __VA_ARGS__); break; \
+        case 4: hipLaunchKernelGGL((KERNEL<4, true>), __VA_ARGS__); break; case 5: hipLaunchKernelGGL((KERNEL<5, true>), __VA_ARGS__); break; \
+        case 6: hipLaunchKernelGGL((KERNEL<6, true>), __VA_ARGS__); break; default: hipLaunchKernelGGL((KERNEL<-1, true>), __VA_ARGS__); } \
+    else RAAE_LAUNCH_KIND(KERNEL, __VA_ARGS__)
 #define RAAE_LAUNCH_KIND(KERNEL, ...) switch (kind) { \
         case 0: hipLaunchKernelGGL(KERNEL<0>, __VA_ARGS__); break; case 1: hipLaunchKernelGGL(KERNEL<1>, __VA_ARGS__); break; \
         case 2: hipLaunchKernelGGL(KERNEL<2>, __VA_ARGS__); break; case 3: hipLaunchKernelGGL(KERNEL<3>, __VA_ARGS__); break; \
@@ -767,7 +781,8 @@ extern "C" int raae_block_fwd_a(const raae_block_fwd_a_t* in, int* nparts, void*
     const int rc = prep_block_fwd_a(in, a, grid, lds, kind);
     if (rc) return rc;
     if (nparts) *nparts = grid;
-    RAAE_LAUNCH_KIND(block_fwd_a_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a)
+    const bool big = a.B >= RAAE_BIG_ROWS;
+    RAAE_LAUNCH_KIND_BIG(block_fwd_a_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a)
     RAAE_LAUNCH_RET();
 }
 
@@ -798,7 +813,8 @@ extern "C" int raae_block_fwd_b(const raae_block_fwd_b_t* in, int* nparts, void*
     const int rc = prep_block_fwd_b(in, a, grid, lds, kind);
     if (rc) return rc;
     if (nparts) *nparts = grid;
-    RAAE_LAUNCH_KIND(block_fwd_b_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a)
+    const bool big = a.B >= RAAE_BIG_ROWS;
+    RAAE_LAUNCH_KIND_BIG(block_fwd_b_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a)
     RAAE_LAUNCH_RET();
 }
 
@@ -855,10 +871,10 @@ extern "C" int raae_block_fwd_a2(const raae_block_fwd_a_t* x, const raae_block_f
     const size_t lds = l1 > l2 ? l1 : l2;
     const dim3 grid(g1 + g2);
     RAAE_FWD_PAIRS(block_fwd_a2_kernel)
-    { const int kind = k1; const raae_block_fwd_a_t& a = k.x;
-      RAAE_LAUNCH_KIND(block_fwd_a_kernel, dim3(g1), dim3(256), l1, (hipStream_t)stream, a) }
-    { const int kind = k2; const raae_block_fwd_a_t& a = k.y;
-      RAAE_LAUNCH_KIND(block_fwd_a_kernel, dim3(g2), dim3(256), l2, (hipStream_t)stream, a) }
+    { const int kind = k1; const raae_block_fwd_a_t& a = k.x; const bool big = a.B >= RAAE_BIG_ROWS;
+      RAAE_LAUNCH_KIND_BIG(block_fwd_a_kernel, dim3(g1), dim3(256), l1, (hipStream_t)stream, a) }
+    { const int kind = k2; const raae_block_fwd_a_t& a = k.y; const bool big = a.B >= RAAE_BIG_ROWS;
+      RAAE_LAUNCH_KIND_BIG(block_fwd_a_kernel, dim3(g2), dim3(256), l2, (hipStream_t)stream, a) }
     RAAE_LAUNCH_RET();
 }
 
@@ -877,10 +893,10 @@ extern "C" int raae_block_fwd_b2(const raae_block_fwd_b_t* x, const raae_block_f
     const size_t lds = l1 > l2 ? l1 : l2;
     const dim3 grid(g1 + g2);
     RAAE_FWD_PAIRS(block_fwd_b2_kernel)
-    { const int kind = k1; const raae_block_fwd_b_t& a = k.x;
-      RAAE_LAUNCH_KIND(block_fwd_b_kernel, dim3(g1), dim3(256), l1, (hipStream_t)stream, a) }
-    { const int kind = k2; const raae_block_fwd_b_t& a = k.y;
-      RAAE_LAUNCH_KIND(block_fwd_b_kernel, dim3(g2), dim3(256), l2, (hipStream_t)stream, a) }
+    { const int kind = k1; const raae_block_fwd_b_t& a = k.x; const bool big = a.B >= RAAE_BIG_ROWS;
+      RAAE_LAUNCH_KIND_BIG(block_fwd_b_kernel, dim3(g1), dim3(256), l1, (hipStream_t)stream, a) }
+    { const int kind = k2; const raae_block_fwd_b_t& a = k.y; const bool big = a.B >= RAAE_BIG_ROWS;
+      RAAE_LAUNCH_KIND_BIG(block_fwd_b_kernel, dim3(g2), dim3(256), l2, (hipStream_t)stream, a) }
     RAAE_LAUNCH_RET();
 }
 #undef RAAE_FWD_PAIRS
@@ -918,7 +934,8 @@ extern "C" int raae_block_bwd_b(const raae_block_bwd_b_t* in, int* nparts, void*
     const int rc = prep_block_bwd_b(in, a, grid, lds, kind);
     if (rc) return rc;
     if (nparts) *nparts = grid;
-    RAAE_LAUNCH_KIND(block_bwd_b_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a)
+    const bool big = a.B >= RAAE_BIG_ROWS;
+    RAAE_LAUNCH_KIND_BIG(block_bwd_b_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a)
     RAAE_LAUNCH_RET();
 }
 
@@ -947,7 +964,8 @@ extern "C" int raae_block_bwd_a(const raae_block_bwd_a_t* in, int* nparts, void*
     const int grid = a.ngroups < 512 ? a.ngroups : 512;
     if (nparts) *nparts = grid;
     const size_t lds = sizeof(float) * ((size_t)a.S * per + wfl);
-    RAAE_LAUNCH_KIND(block_bwd_a_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a)
+    const bool big = a.B >= RAAE_BIG_ROWS;
+    RAAE_LAUNCH_KIND_BIG(block_bwd_a_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a)
     RAAE_LAUNCH_RET();
 }
 
@@ -1026,7 +1044,8 @@ extern "C" int raae_block_wgrad(const raae_block_wgrad_t* in, int* nslab, void* 
     size_t dyn;
     const int rc = prep_block_wgrad(in, nslab, m, total, dyn, kind);
     if (rc) return rc;
-    RAAE_LAUNCH_KIND(wgrad_multi_kernel, dim3(total), dim3(256), dyn, (hipStream_t)stream, m)
+    const bool big = in->B >= RAAE_BIG_ROWS;
+    RAAE_LAUNCH_KIND_BIG(wgrad_multi_kernel, dim3(total), dim3(256), dyn, (hipStream_t)stream, m)
     RAAE_LAUNCH_RET();
 }
 

@@ -11,6 +11,7 @@
 // (raae_disc_input, 3 x raae_dense_fwd, raae_bce_pair_fwd_bwd, 3 x raae_dense_bwd, raae_scale_by_dev), which at
 // 256-row batches cost ~50 us for ~7 MFLOP.  Instance: hidden width 64, three layers, nstyle <= 16.
 #include "raae_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -35,6 +36,13 @@ struct DiscArgs {
 
 __device__ __forceinline__ double softplus_dd(double x) { return x > 0.0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
 
+// MM: the three 64 x 64 contractions of a tile (layer 2 forward, dW2 += G2^T A1, dA1 = G2 W2) run on the matrix cores
+// (v_mfma_f32_16x16x4_f32: exact fp32; operand a = A[row = lane & 15][k = lane >> 4], b = B[k = lane >> 4][col =
+// lane & 15], result c[j] = C[row = 4 (lane >> 4) + j][col = lane & 15]); each wave owns 16 of the 64 output columns
+// (rows of dW2).  Used from 2048 rows up, where the discriminator is a real contraction (BASELINE configs[2]:
+// 8192 x 64 x 64 per layer); below that the step is launch-bound and the VALU form keeps its thread mapping from
+// load to epilogue without the extra LDS round trip.
+template <bool MM>
 __global__ __launch_bounds__(256) void disc_fused_kernel(DiscArgs a) {
     __shared__ float W1[DH * DNS], W2[DH * (DH + 1)], W3[DH], B1[DH], B2[DH], S1[DH], S2[DH];
     __shared__ float X[DT * DNS], Z1[DT * AP], A1[DT * AP], Z2[DT * AP], A2[DT * AP], G2[DT * AP], G1[DT * AP];
@@ -51,6 +59,10 @@ __global__ __launch_bounds__(256) void disc_fused_kernel(DiscArgs a) {
     const float neg_alpha = -a.alpha[0];
     // per-thread accumulators of the parameter gradients over this workgroup's tiles
     float aw2[16], aw1[4];
+    f32x4 mw2[4];                                         // MM: dW2 tiles (rows 16 wave + 4 (lane >> 4) + j, columns 16 tk + (lane & 15))
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mw2[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int lane = t & 63, wave = t >> 6, l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
     for (int i = 0; i < 16; ++i) aw2[i] = 0.f;
 #pragma unroll
@@ -99,11 +111,24 @@ __global__ __launch_bounds__(256) void disc_fused_kernel(DiscArgs a) {
         {
             const int row = row0 + r4;
             float acc[4] = {B2[c4], B2[c4 + 1], B2[c4 + 2], B2[c4 + 3]};
-#pragma unroll 4
-            for (int k = 0; k < DH; ++k) {
-                const float x = A1[r4 * AP + k];
+            if constexpr (MM) {
+                f32x4 c = {0.f, 0.f, 0.f, 0.f};
+                const float* pa = A1 + l15 * AP + l4;
+                const float* pb = W2 + (16 * wave + l15) * (DH + 1) + l4;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = fmaf(x, W2[(c4 + j) * (DH + 1) + k], acc[j]);
+                for (int q = 0; q < DH / 4; ++q) c = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * q], pb[4 * q], c, 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Z2[(4 * l4 + j) * AP + 16 * wave + l15] = c[j];
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] += Z2[r4 * AP + c4 + j];
+            } else {
+#pragma unroll 4
+                for (int k = 0; k < DH; ++k) {
+                    const float x = A1[r4 * AP + k];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = fmaf(x, W2[(c4 + j) * (DH + 1) + k], acc[j]);
+                }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -156,20 +181,45 @@ __global__ __launch_bounds__(256) void disc_fused_kernel(DiscArgs a) {
         }
         if (t == 64) { float b = 0.f; for (int r = 0; r < DT; ++r) b += DL[r]; ab3 += b; }
         // dW2[o][k] += sum_r G2[r][o] A1[r][k]
-#pragma unroll 2
-        for (int r = 0; r < DT; ++r) {
-            const float g = G2[r * AP + wo];
+        if constexpr (MM) {
+            // A = G2^T: a = G2[r = 4 q + (lane >> 4)][o = 16 wave + (lane & 15)], b = A1[r][k = 16 tk + (lane & 15)]
 #pragma unroll
-            for (int j = 0; j < 16; ++j) aw2[j] = fmaf(g, A1[r * AP + wk + j], aw2[j]);
+            for (int q = 0; q < DT / 4; ++q) {
+                const float ga = G2[(4 * q + l4) * AP + 16 * wave + l15];
+#pragma unroll
+                for (int tk = 0; tk < 4; ++tk)
+                    mw2[tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga, A1[(4 * q + l4) * AP + 16 * tk + l15], mw2[tk], 0, 0, 0);
+            }
+        } else {
+#pragma unroll 2
+            for (int r = 0; r < DT; ++r) {
+                const float g = G2[r * AP + wo];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) aw2[j] = fmaf(g, A1[r * AP + wk + j], aw2[j]);
+            }
         }
         // dA1 = G2 W2 ; through mask1 and PReLU1 -> G1 = dZ1 (Z1 turns into the slope-gradient terms)
         {
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-            for (int o = 0; o < DH; ++o) {
-                const float g = G2[r4 * AP + o];
+            if constexpr (MM) {
+                f32x4 c = {0.f, 0.f, 0.f, 0.f};
+                const float* pa = G2 + l15 * AP + l4;                       // A[row r][k = o]
+                const float* pb = W2 + l4 * (DH + 1) + 16 * wave + l15;     // B[k = o][col = input feature]
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = fmaf(g, W2[o * (DH + 1) + c4 + j], acc[j]);
+                for (int q = 0; q < DH / 4; ++q)
+                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * q], pb[4 * q * (DH + 1)], c, 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) G1[(4 * l4 + j) * AP + 16 * wave + l15] = c[j];
+                __syncthreads();                         // dA1 tile complete; dW2 above has read A1
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = G1[r4 * AP + c4 + j];
+            } else {
+#pragma unroll 4
+                for (int o = 0; o < DH; ++o) {
+                    const float g = G2[r4 * AP + o];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = fmaf(g, W2[o * (DH + 1) + c4 + j], acc[j]);
+                }
             }
             __syncthreads();                             // dW2 above still reads A1
 #pragma unroll
@@ -214,8 +264,15 @@ __global__ __launch_bounds__(256) void disc_fused_kernel(DiscArgs a) {
     }
     // ---- this workgroup's slab of parameter gradients
     const size_t slab = (size_t)blockIdx.x * (size_t)a.slab_stride;
+    if constexpr (MM) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) a.dw2[slab + wo * DH + wk + j] = aw2[j];
+        for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a.dw2[slab + (16 * wave + 4 * l4 + j) * DH + 16 * tk + l15] = mw2[tk][j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a.dw2[slab + wo * DH + wk + j] = aw2[j];
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const int idx = t + 256 * j; if (idx < DH * ns) a.dw1[slab + idx] = aw1[j]; }
     if (t < DH) {
@@ -256,6 +313,10 @@ extern "C" int raae_disc_fused(const raae_disc_fused_t* in, int* nslab, void* st
     const int ntiles = (in->n_real + in->n_fake + DT - 1) / DT;
     const int grid = ntiles < 256 ? ntiles : 256;
     if (nslab) *nslab = grid;
-    hipLaunchKernelGGL(disc_fused_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    // from 2048 rows (real + fake) the 64 x 64 layers go through the matrix cores; RAAE_DISC_MFMA=0/1 forces a form
+    static const int force = [] { const char* e = getenv("RAAE_DISC_MFMA"); return e ? atoi(e) : -1; }();
+    const bool mm = force >= 0 ? force != 0 : (in->n_real + in->n_fake >= 2048);
+    if (mm) hipLaunchKernelGGL(disc_fused_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(disc_fused_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     RAAE_LAUNCH_RET();
 }

@@ -641,23 +641,44 @@ def test_disc_fused_matches_autograd(n_real, n_fake, ns, drop):
                          torch.zeros(1, dtype=torch.int32, device=DEV), out)
     assert 1 <= nsl <= 256
     close(out, loss.detach().view(1), 1e-5, 1e-6, "loss")
-    # dstyles: a hidden unit whose pre-activation is pure rounding residue can take the other PReLU slope here than
-    # in the torch reference (another summation order): that moves ONE row; up to three such rows are tolerated
+    # A hidden unit whose pre-activation is pure rounding residue can take the other PReLU slope here than in the torch
+    # reference (another summation order).  That is VERIFIED, not assumed: the rows that hold such a unit are found
+    # from a float64 repeat of the forward (|z| < 1e-5 max|z| in either hidden layer); only those rows may miss the
+    # tight tolerance, and without any such row nothing may.
+    with torch.no_grad():
+        z1 = x.detach().double() @ lin[0].weight.double().T + lin[0].bias.double()
+        a1 = torch.where(z1 > 0, z1, z1 * pre[0].weight.double())
+        if masks[0] is not None:
+            a1 = a1 * masks[0].double()
+        z2 = a1 @ lin[1].weight.double().T + lin[1].bias.double()
+        near = ((z1.abs() < 1e-5 * z1.abs().max()).any(1) | (z2.abs() < 1e-5 * z2.abs().max()).any(1)).numpy()
+    near_rows = set(int(i) - n_real for i in np.nonzero(near)[0] if i >= n_real)
+    n_near = int(near.sum())
     want = (-alpha * styles.grad).double().numpy()
     err = np.abs(dstyles.cpu().double().numpy() - want)
     tol = 1e-7 + 2e-4 * float(np.abs(want).max()) + 2e-4 * np.abs(want)
-    bad_rows = np.unique(np.nonzero(err > tol)[0])
-    assert len(bad_rows) <= 3 and (err[bad_rows] <= 0.5 * np.abs(want).max()).all(), (bad_rows, err.max())
+    bad_rows = set(int(i) for i in np.unique(np.nonzero(err > tol)[0]))
+    assert bad_rows <= near_rows, (sorted(bad_rows), sorted(near_rows), err.max())
+    assert all((err[r_] <= 0.5 * np.abs(want).max()).all() for r_ in bad_rows)
     ref = [lin[0].weight.grad, lin[0].bias.grad, pre[0].weight.grad, lin[1].weight.grad, lin[1].bias.grad,
            pre[1].weight.grad, lin[2].weight.grad, lin[2].bias.grad]
     for q, r, name in zip(params, ref, ["dw1", "db1", "ds1", "dw2", "db2", "ds2", "dw3", "db3"]):
         got = slabs[:nsl, offs[id(q)]:offs[id(q)] + q.numel()].sum(0).view(r.shape)
-        # (the same slope flip reaches the gradient entries of that hidden unit: a few entries may miss the tight
-        # tolerance, by a few percent of the tensor's largest entry at most)
+        # (a flipped unit of row r reaches, through that row, one row of dW2 and every entry of dW1: up to ~130 entries
+        # per flip may miss the tight tolerance, by a few percent of the tensor's largest entry at most)
         e = (got.cpu().double() - r.double()).abs().numpy()
         rmax = float(r.abs().max())
         t = 1e-7 + 2e-4 * rmax + 2e-4 * r.abs().double().numpy()
-        assert (e > t).sum() <= 3 * 130 and e.max() <= 0.05 * rmax + 1e-7, (name, int((e > t).sum()), e.max(), rmax)
+        n_bad = int((e > t).sum())
+        assert n_bad <= n_near * 130 and (n_bad == 0 or e.max() <= 0.05 * rmax + 1e-7), (name, n_bad, n_near, e.max(), rmax)
+
+
+@pytest.mark.parametrize("n_real,n_fake", [(1024, 1024), (4096, 4100)])
+def test_disc_fused_matrix_core_form(n_real, n_fake):
+    """From 2048 rows (real + fake) the three 64 x 64 contractions of raae_disc_fused run on the matrix cores
+    (v_mfma_f32_16x16x4_f32, the MM instance of the kernel); below that the VALU instance runs, which the cases above
+    pin at 63 .. 512 rows.  The matrix-core instance at 2048 and 8196 rows against torch autograd, same tolerances."""
+    test_disc_fused_matches_autograd(n_real, n_fake, 6, True)
 
 
 def test_loss_kernels_finish_in_kernel():
