@@ -69,8 +69,21 @@ int raae_dense_fwd(const float* x, int B, int K, int in_kind, const float* slope
 typedef struct {
     const float* x; int B, K, in_kind; const float* slope; int has_bn; raae_bn_t bn; const float* mask;
     const float* w; const float* bias; int N; float* z; int out_kind; const float* out_slope; double* out_partials;
+    int storage;          /* RAAE_ST_* bits: which tensors are stored as bf16 (0: all fp32) */
 } raae_dense_fwd_t;
 int raae_dense_fwd2(const raae_dense_fwd_t* p, const raae_dense_fwd_t* q, int* nparts_p, int* nparts_q, void* stream);
+
+/* bf16 STORAGE of activations and dropout multipliers (build-only config key `precision: bf16`, BASELINE configs[4]:
+ * 512-point spectra + 12 descriptors, mixed precision).  The reference arithmetic is fp32
+ * (sc/clustering/dataloader.py:61); this mode halves the bytes of the [B][hidden] activations and masks while every
+ * product, sum, BatchNorm statistic, gradient and Adam moment stays fp32 / double.  A set bit means the tensor behind
+ * the (still float*-typed) pointer holds bf16 values; the layer output is rounded (nearest even) before its
+ * BatchNorm statistics are taken.  storage == 0 is the fp32 path, instruction for instruction. */
+enum { RAAE_ST_X = 1,            /* layer input x                    */
+       RAAE_ST_MASK = 2,         /* dropout multipliers of the input */
+       RAAE_ST_Z = 4 };          /* raw layer output z (forward) / zout (backward) */
+/* raae_dense_fwd from a raae_dense_fwd_t, honouring `storage` */
+int raae_dense_fwd_s(const raae_dense_fwd_t* p, int* out_nparts, void* stream);
 
 /* how the gradient w.r.t. this layer's raw output z is obtained in the prologue */
 enum { RAAE_G_DIRECT = 0,        /* g is dL/dz                                                  */
@@ -98,6 +111,13 @@ int raae_dense_bwd(const float* g, int g_kind, const double* g_partials, int g_n
                    const float* mask, const float* w,
                    float* dw, float* db, float* dslope, long slab_stride, int* nslab,
                    float* dx, double* dx_partials, void* stream);
+/* the same with bf16 storage bits (RAAE_ST_X: x, RAAE_ST_MASK: mask, RAAE_ST_Z: zout) */
+int raae_dense_bwd_st(const float* g, int g_kind, const double* g_partials, int g_nparts, const float* zout,
+                   const float* out_slope, const raae_bn_t* out_bn, int B, int N,
+                   const float* x, int K, int in_kind, const float* slope, const raae_bn_t* bn,
+                   const float* mask, const float* w,
+                   float* dw, float* db, float* dslope, long slab_stride, int* nslab,
+                   float* dx, double* dx_partials, int storage, void* stream);
 
 /* Final BatchNorm1d(nstyle, affine=False) of both encoders (model.py:284,366):
  * styles = BN(z).  Backward: dz from dstyles (torch batch_norm backward, train mode). */

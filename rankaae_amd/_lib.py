@@ -27,7 +27,10 @@ class DenseFwdT(C.Structure):
     _fields_ = [("x", C.c_void_p), ("B", C.c_int), ("K", C.c_int), ("in_kind", C.c_int), ("slope", C.c_void_p),
                 ("has_bn", C.c_int), ("bn", BnT), ("mask", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p),
                 ("N", C.c_int), ("z", C.c_void_p), ("out_kind", C.c_int), ("out_slope", C.c_void_p),
-                ("out_partials", C.c_void_p)]
+                ("out_partials", C.c_void_p), ("storage", C.c_int)]
+
+
+ST_X, ST_MASK, ST_Z = 1, 2, 4        # RAAE_ST_*: bf16 storage bits of the dense kernels
 
 
 class DiscFusedT(C.Structure):
@@ -138,6 +141,8 @@ SIGNATURES = {
     "raae_dense_fwd": (_I, [_P, _I, _I, _I, _P, _PB, _P, _P, _P, _I, _P, _I, _P, _P, _PI, _P]),
     "raae_dense_bwd": (_I, [_P, _I, _P, _I, _P, _P, _PB, _I, _I, _P, _I, _I, _P, _PB, _P, _P,
                             _P, _P, _P, _L, _PI, _P, _P, _P]),
+    "raae_dense_bwd_st": (_I, [_P, _I, _P, _I, _P, _P, _PB, _I, _I, _P, _I, _I, _P, _PB, _P, _P,
+                               _P, _P, _P, _L, _PI, _P, _P, _I, _P]),
     "raae_style_bn_fwd": (_I, [_P, _I, _I, _PB, _P, _P]),
     "raae_style_bn_bwd": (_I, [_P, _P, _I, _I, _PB, _F, _P, _P]),
     "raae_rank_loss_work_bytes": (_L, [_I, _I]),
@@ -167,6 +172,7 @@ SIGNATURES = {
     "raae_block_fwd_b": (_I, [C.POINTER(BlockFwdBT), _PI, _P]),
     "raae_disc_fused": (_I, [C.POINTER(DiscFusedT), _PI, _P]),
     "raae_dense_fwd2": (_I, [C.POINTER(DenseFwdT), C.POINTER(DenseFwdT), _PI, _PI, _P]),
+    "raae_dense_fwd_s": (_I, [C.POINTER(DenseFwdT), _PI, _P]),
     "raae_block_fwd_a2": (_I, [C.POINTER(BlockFwdAT), C.POINTER(BlockFwdAT), _PI, _PI, _P]),
     "raae_block_fwd_b2": (_I, [C.POINTER(BlockFwdBT), C.POINTER(BlockFwdBT), _PI, _PI, _P]),
     "raae_block_bwd_b": (_I, [C.POINTER(BlockBwdBT), _PI, _P]),

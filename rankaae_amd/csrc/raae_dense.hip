@@ -11,6 +11,7 @@
 // statistics and parameter gradients leave the kernel as fixed-order per-workgroup
 // partials (double) / slabs (float): no atomics, bitwise reproducible.
 #include "raae_common.h"
+#include <hip/hip_bf16.h>
 
 namespace {
 
@@ -19,8 +20,27 @@ using raae::prelu;
 struct DenseFwdArgs {
     const float* x; int B; int K; int in_kind; const float* slope; raae_bn_t bn; const float* mask;
     const float* w; const float* bias; int N; float* z; int out_kind; const float* out_slope;
-    double* out_partials; int pitch;
+    double* out_partials; int pitch; int storage;
 };
+
+// ---- bf16 STORAGE of activations and dropout multipliers (`precision: bf16`, BASELINE configs[4]) ----------------
+// RAAE_ST_X / _MASK / _Z: the layer input / its dropout multipliers / the layer's raw output live in memory as bf16
+// (the pointers are still typed float*).  Everything is converted to fp32 on load and all arithmetic, statistics and
+// accumulators stay fp32 / double; the output is rounded to bf16 (round to nearest even: v_cvt_pk_bf16_f32) BEFORE its
+// BatchNorm statistics are taken, so that the statistics describe the values the next layer will read.
+// With storage == 0 no instruction of the fp32 path changes.
+__device__ __forceinline__ float bf16_at(const float* p, size_t i) {
+    return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(p)[i] << 16);
+}
+__device__ __forceinline__ float4 bf16x4_at(const float* p, size_t i) {        // i a multiple of 4
+    const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p) + i);
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                       __uint_as_float(v.y & 0xffff0000u));
+}
+__device__ __forceinline__ float bf16_round(float v) { return __bfloat162float(__float2bfloat16(v)); }
+__device__ __forceinline__ void bf16_store(float* p, size_t i, float v) {
+    reinterpret_cast<__hip_bfloat16*>(p)[i] = __float2bfloat16(v);
+}
 
 // Input transform of one element (PReLU -> BatchNorm -> Dropout scale), statistics from LDS.
 __device__ __forceinline__ float in_transform(float v, int k, int in_kind, const float* s_slope, const float* s_mean,
@@ -36,8 +56,9 @@ __device__ __forceinline__ float in_transform(float v, int k, int in_kind, const
 // Vector path (K % 4 == 0): one float4 per thread per pass, no integer division in the loop.
 __device__ __forceinline__ void stage_rows(float* Xs, int pitch, const float* x, const float* mask, int row0, int B,
                                            int K, int K4, int in_kind, const float* s_slope, const float* s_mean,
-                                           const float* s_rstd) {
+                                           const float* s_rstd, int storage = 0) {
     const int tid = threadIdx.x;
+    const bool xb = (storage & RAAE_ST_X) != 0, mb = (storage & RAAE_ST_MASK) != 0;
     if ((K & 3) == 0) {
         const int kq = K >> 2;                       // float4s per row
         int r = tid / kq, c4 = tid - r * kq;
@@ -46,13 +67,14 @@ __device__ __forceinline__ void stage_rows(float* Xs, int pitch, const float* x,
             const int row = row0 + r, k = c4 << 2;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < B) {
-                v = *reinterpret_cast<const float4*>(x + (size_t)row * K + k);
+                v = xb ? bf16x4_at(x, (size_t)row * K + k) : *reinterpret_cast<const float4*>(x + (size_t)row * K + k);
                 v.x = in_transform(v.x, k, in_kind, s_slope, s_mean, s_rstd);
                 v.y = in_transform(v.y, k + 1, in_kind, s_slope, s_mean, s_rstd);
                 v.z = in_transform(v.z, k + 2, in_kind, s_slope, s_mean, s_rstd);
                 v.w = in_transform(v.w, k + 3, in_kind, s_slope, s_mean, s_rstd);
                 if (in_kind != RAAE_IN_NONE && mask) {
-                    const float4 m = *reinterpret_cast<const float4*>(mask + (size_t)row * K + k);
+                    const float4 m = mb ? bf16x4_at(mask, (size_t)row * K + k)
+                                        : *reinterpret_cast<const float4*>(mask + (size_t)row * K + k);
                     v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
                 }
             }
@@ -68,8 +90,9 @@ __device__ __forceinline__ void stage_rows(float* Xs, int pitch, const float* x,
             const int row = row0 + r;
             float v = 0.f;
             if (row < B && k < K) {
-                v = in_transform(x[(size_t)row * K + k], k, in_kind, s_slope, s_mean, s_rstd);
-                if (in_kind != RAAE_IN_NONE && mask) v *= mask[(size_t)row * K + k];
+                const size_t o = (size_t)row * K + k;
+                v = in_transform(xb ? bf16_at(x, o) : x[o], k, in_kind, s_slope, s_mean, s_rstd);
+                if (in_kind != RAAE_IN_NONE && mask) v *= mb ? bf16_at(mask, o) : mask[o];
             }
             Xs[r * pitch + k] = v;
         }
@@ -116,7 +139,7 @@ __device__ __forceinline__ void dense_fwd_body(const DenseFwdArgs& a, const int 
 
     for (int tile = bx; tile < ntiles; tile += gx) {
         const int row0 = tile << 4;
-        stage_rows(Xs, a.pitch, a.x, a.mask, row0, a.B, a.K, K4, a.in_kind, s_slope, s_mean, s_rstd);
+        stage_rows(Xs, a.pitch, a.x, a.mask, row0, a.B, a.K, K4, a.in_kind, s_slope, s_mean, s_rstd, a.storage);
         __syncthreads();
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -129,11 +152,13 @@ __device__ __forceinline__ void dense_fwd_body(const DenseFwdArgs& a, const int 
             for (int j = 0; j < 4; ++j) {
                 const int row = row0 + (lane >> 4) * 4 + j;
                 if (row < a.B) {
-                    const float zv = acc[j] + bias;
+                    float zv = acc[j] + bias;
+                    if (a.storage & RAAE_ST_Z) zv = bf16_round(zv);
                     float o = zv;
                     if (a.out_kind == RAAE_OUT_SOFTPLUS) o = raae::softplus2(zv);
                     else if (a.out_kind == RAAE_OUT_RELU) o = fmaxf(zv, 0.f);
-                    a.z[(size_t)row * a.N + col] = o;
+                    if (a.storage & RAAE_ST_Z) bf16_store(a.z, (size_t)row * a.N + col, o);
+                    else a.z[(size_t)row * a.N + col] = o;
                     if (a.out_kind == RAAE_OUT_STATS_PRELU || a.out_kind == RAAE_OUT_STATS_RAW) {
                         const float v = (a.out_kind == RAAE_OUT_STATS_PRELU) ? prelu(zv, oslope) : zv;
                         s_acc += (double)v;
@@ -179,7 +204,7 @@ struct DenseBwdArgs {
     const float* out_slope; raae_bn_t out_bn; int B; int N;
     const float* x; int K; int in_kind; const float* slope; raae_bn_t bn; const float* mask; const float* w;
     float* dw; float* db; float* dslope; long slab_stride; float* dx; double* dx_partials;
-    int pitch_g; int pitch_x;
+    int pitch_g; int pitch_x; int storage;      // RAAE_ST_X: x, RAAE_ST_MASK: mask, RAAE_ST_Z: zout are bf16
 };
 
 // TPW: 16x16 dW tiles per wave; KT4: 16-column dx tiles per wave.
@@ -237,6 +262,7 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
     const int grstep = wideN ? 1 : 4;
     double db_acc[2] = {0.0, 0.0}, ds_acc[2] = {0.0, 0.0};
 
+    const bool zb = (a.storage & RAAE_ST_Z) != 0;
     const int ntiles = (a.B + 15) >> 4;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile << 4;
@@ -256,7 +282,7 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
                     else if (a.g_kind == RAAE_G_SOFTPLUS) dz = gv * (1.f - expf(-2.f * a.zout[o]));
                     else if (a.g_kind == RAAE_G_RELU) dz = a.zout[o] > 0.f ? gv : 0.f;
                     else {
-                        const float zv = a.zout[o];
+                        const float zv = zb ? bf16_at(a.zout, o) : a.zout[o];
                         float da = gv;
                         if (a.g_kind == RAAE_G_PRELU_BN) {
                             const float y = (prelu(zv, o_slope[n]) - o_mean[n]) * o_rstd[n];
@@ -271,7 +297,7 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
             }
         }
         // ---- 2. layer input tile -> Xs (transform applied) ----
-        stage_rows(Xs, a.pitch_x, a.x, a.mask, row0, a.B, a.K, K16, a.in_kind, i_slope, i_mean, i_rstd);
+        stage_rows(Xs, a.pitch_x, a.x, a.mask, row0, a.B, a.K, K16, a.in_kind, i_slope, i_mean, i_rstd, a.storage);
         __syncthreads();
         // ---- 3. dW[n][k] += sum_rows dz[row][n] * xin[row][k]; wave owns tiles t = wv + 4 i ----
 #pragma unroll
@@ -328,10 +354,11 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
                             if (row < a.B) {
                                 const size_t o = (size_t)row * a.K + kcol;
                                 float d = acc[j];
-                                if (a.in_kind != RAAE_IN_NONE && a.mask) d *= a.mask[o];
+                                if (a.in_kind != RAAE_IN_NONE && a.mask) d *= (a.storage & RAAE_ST_MASK) ? bf16_at(a.mask, o) : a.mask[o];
                                 a.dx[o] = d;
                                 if (a.dx_partials != nullptr) {
-                                    const float y = (prelu(a.x[o], i_slope[kcol]) - i_mean[kcol]) * i_rstd[kcol];
+                                    const float xv = (a.storage & RAAE_ST_X) ? bf16_at(a.x, o) : a.x[o];
+                                    const float y = (prelu(xv, i_slope[kcol]) - i_mean[kcol]) * i_rstd[kcol];
                                     dxs[i] += (double)d;
                                     dxq[i] += (double)d * (double)y;
                                 }
@@ -416,6 +443,7 @@ static int prep_dense_fwd(const float* x, int B, int K, int in_kind, const float
     RAAE_CHECK_ARG(a.bn.nparts >= 0 && a.bn.nparts <= RAAE_MAX_PARTS);
     a.w = w; a.bias = bias; a.N = N; a.z = z; a.out_kind = out_kind; a.out_slope = out_slope;
     a.out_partials = out_partials;
+    a.storage = 0;
     const int K4 = (K + 3) & ~3;
     RAAE_CHECK_ARG(K4 <= 512 && (in_kind != RAAE_IN_PRELU_BN_DROP || K <= 256));
     a.pitch = K4 + 2;
@@ -447,6 +475,23 @@ extern "C" int raae_dense_fwd(const float* x, int B, int K, int in_kind, const f
     RAAE_LAUNCH_RET();
 }
 
+// struct form of raae_dense_fwd; honours p->storage (bf16 storage of x / mask / z)
+extern "C" int raae_dense_fwd_s(const raae_dense_fwd_t* p, int* out_nparts, void* stream) {
+    RAAE_CHECK_ARG(p && (p->storage & ~(RAAE_ST_X | RAAE_ST_MASK | RAAE_ST_Z)) == 0);
+    RAAE_CHECK_ARG(!(p->storage & RAAE_ST_X) || (p->K & 3) == 0);
+    DenseFwdArgs a;
+    dim3 grid;
+    size_t lds;
+    int kq;
+    const int rc = prep_dense_fwd(p->x, p->B, p->K, p->in_kind, p->slope, p->has_bn ? &p->bn : nullptr, p->mask, p->w,
+                                  p->bias, p->N, p->z, p->out_kind, p->out_slope, p->out_partials, a, grid, lds, kq);
+    if (rc) return rc;
+    a.storage = p->storage;
+    if (out_nparts) *out_nparts = (int)grid.x;
+    launch_dense_fwd(a, grid, lds, kq, (hipStream_t)stream);
+    RAAE_LAUNCH_RET();
+}
+
 extern "C" int raae_dense_fwd2(const raae_dense_fwd_t* p, const raae_dense_fwd_t* q, int* nparts_p, int* nparts_q,
                                void* stream) {
     RAAE_CHECK_ARG(p && q);
@@ -460,6 +505,7 @@ extern "C" int raae_dense_fwd2(const raae_dense_fwd_t* p, const raae_dense_fwd_t
     rc = prep_dense_fwd(q->x, q->B, q->K, q->in_kind, q->slope, q->has_bn ? &q->bn : nullptr, q->mask, q->w, q->bias,
                         q->N, q->z, q->out_kind, q->out_slope, q->out_partials, k.y, g2, l2, q2);
     if (rc) return rc;
+    k.x.storage = p->storage; k.y.storage = q->storage;
     if (nparts_p) *nparts_p = (int)g1.x;
     if (nparts_q) *nparts_q = (int)g2.x;
     hipStream_t st = (hipStream_t)stream;
@@ -483,6 +529,17 @@ extern "C" int raae_dense_bwd(const float* g, int g_kind, const double* g_partia
                               const float* mask, const float* w,
                               float* dw, float* db, float* dslope, long slab_stride, int* nslab,
                               float* dx, double* dx_partials, void* stream) {
+    return raae_dense_bwd_st(g, g_kind, g_partials, g_nparts, zout, out_slope, out_bn, B, N, x, K, in_kind, slope, bn, mask, w,
+                             dw, db, dslope, slab_stride, nslab, dx, dx_partials, 0, stream);
+}
+
+extern "C" int raae_dense_bwd_st(const float* g, int g_kind, const double* g_partials, int g_nparts, const float* zout,
+                                 const float* out_slope, const raae_bn_t* out_bn, int B, int N,
+                                 const float* x, int K, int in_kind, const float* slope, const raae_bn_t* bn,
+                                 const float* mask, const float* w,
+                                 float* dw, float* db, float* dslope, long slab_stride, int* nslab,
+                                 float* dx, double* dx_partials, int storage, void* stream) {
+    RAAE_CHECK_ARG((storage & ~(RAAE_ST_X | RAAE_ST_MASK | RAAE_ST_Z)) == 0 && (!(storage & RAAE_ST_X) || (K & 3) == 0));
     RAAE_CHECK_ARG(g && x && w && dw && db && B > 0 && N > 0 && K > 0 && N <= 512 && K <= 512);
     RAAE_CHECK_ARG(g_kind >= 0 && g_kind <= 4 && in_kind >= 0 && in_kind <= 2);
     RAAE_CHECK_ARG(g_kind == RAAE_G_DIRECT || zout);
@@ -503,6 +560,7 @@ extern "C" int raae_dense_bwd(const float* g, int g_kind, const double* g_partia
     a.dx = dx; a.dx_partials = (in_kind == RAAE_IN_PRELU_BN_DROP) ? dx_partials : nullptr;
     const int N16 = (N + 15) & ~15, K16 = (K + 15) & ~15;
     a.pitch_g = N16 + 2; a.pitch_x = K16 + 2;
+    a.storage = storage;
     const int tiles = (N16 / 16) * (K16 / 16);
     const int tpw = (tiles + 3) / 4, kt4 = (K16 / 16 + 3) / 4;
     const size_t lds = sizeof(float) * (5 * (size_t)N16 + 3 * (size_t)K16 + 16 * (size_t)(a.pitch_g + a.pitch_x) + 512);

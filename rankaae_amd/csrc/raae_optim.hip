@@ -155,6 +155,19 @@ __global__ __launch_bounds__(256) void rng_fill_kernel(float* tape, const int* s
         uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)ctr, (uint32_t)(ctr >> 32)};
         philox(c, (uint32_t)seed, (uint32_t)(seed >> 32));
         float o[4];
+        if (kind == 2) {
+            // dropout multipliers stored as bf16 (`precision: bf16`): this thread's four floats hold eight of them;
+            // a second Philox block (counter word 1 with its top bit set) supplies draws five to eight
+            uint32_t c2[4] = {(uint32_t)q, (uint32_t)(q >> 32) | 0x80000000u, (uint32_t)ctr, (uint32_t)(ctr >> 32)};
+            philox(c2, (uint32_t)seed, (uint32_t)(seed >> 32));
+            const float keep = seg_scale[lo];
+            const uint32_t one = (uint32_t)(__float_as_uint(1.f / keep) + 0x7fffu + ((__float_as_uint(1.f / keep) >> 16) & 1u)) >> 16;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t lo16 = u01(c[j]) < keep ? one : 0u, hi16 = u01(c2[j]) < keep ? one : 0u;
+                o[j] = __uint_as_float(lo16 | (hi16 << 16));       // elements 2 (e0 + j), 2 (e0 + j) + 1 of the bf16 view
+            }
+        } else
         if (kind == 0) {
             const float r0 = sqrtf(-2.f * logf(u01(c[0]))), r1 = sqrtf(-2.f * logf(u01(c[2])));
             const float a0 = 6.283185307179586f * u01(c[1]), a1 = 6.283185307179586f * u01(c[3]);

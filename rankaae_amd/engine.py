@@ -98,9 +98,12 @@ class Tape:
         self.buf = None
 
     def slot(self, count, kind, keep=1.0):
+        """``kind`` 0: N(0,1) floats; 1: dropout multipliers (0 or 1/keep) as floats; 2: the same stored as bf16
+        (``precision: bf16``) -- ``count`` values in ``(count + 1) // 2`` floats of the buffer."""
         off = self.total
-        self.segs.append((off, count, kind, keep))
-        self.total += (count + 3) // 4 * 4
+        nfloat = (count + 1) // 2 if kind == 2 else count
+        self.segs.append((off, nfloat, kind, keep))
+        self.total += (nfloat + 3) // 4 * 4
         return off
 
     def draw(self, kind, off, shape, keep=1.0):
@@ -117,6 +120,11 @@ class Tape:
         n = int(np.prod(shape))
         return self.buf[off:off + n].view(*shape)
 
+    def view16(self, off, *shape):
+        """bf16 view of a kind-2 slot."""
+        n = int(np.prod(shape))
+        return self.buf[off:off + (n + 1) // 2].view(torch.bfloat16)[:n].view(*shape)
+
     def fill_host(self):
         """Parity mode: draw from the GLOBAL torch CPU generator exactly as the reference's
         ``randn_like`` / ``nn.Dropout`` / ``randn`` calls would (finding 9)."""
@@ -126,6 +134,9 @@ class Tape:
                 self.host[off:off + n] = torch.randn(*shape).reshape(-1)
             elif kind == "mask":
                 self.host[off:off + n] = torch.empty(*shape).bernoulli_(keep).div_(keep).reshape(-1)
+            elif kind == "mask16":      # the same draw, stored as bf16
+                m16 = torch.empty(*shape).bernoulli_(keep).div_(keep).reshape(-1).to(torch.bfloat16)
+                self.host[off:off + (n + 1) // 2].view(torch.bfloat16)[:n] = m16
             else:
                 raise ValueError(kind)
         self.buf.copy_(self.host, non_blocking=True)
@@ -165,12 +176,20 @@ class FCNet:
         self.final_relu = kind == "dec" and isinstance(module.main[-1], nn.ReLU)
         self.bn_modules = [l.bn for l in self.layers if l.bn is not None]
         self.pairable = True       # forward_steps yields at every layer, the first time before anything is written
+        # `precision: bf16`: hidden activations and dropout multipliers are STORED as bf16 (all arithmetic fp32)
+        self.bf16 = bool(getattr(eng, "bf16", False))
 
     def alloc(self, b):
         dev = self.eng.device
         ws = type("WS", (), {})()
         ws.b = b
-        ws.z = [torch.empty(b, l.N, device=dev) for l in self.layers]
+        hid = torch.bfloat16 if self.bf16 else torch.float32
+        # (first and last layer outputs stay fp32: the first layer sees the un-normalised input -- spectra that differ
+        # by a fraction of a percent -- so its pre-activations vary by less than a bf16 step across the batch and the
+        # BatchNorm behind them would amplify the rounding to O(1): measured, 40-70 % gradient error; every deeper
+        # layer reads BatchNorm-normalised inputs.  The last layer feeds the losses.)
+        ws.z = [torch.empty(b, l.N, device=dev, dtype=hid if 0 < i < len(self.layers) - 1 else torch.float32)
+                for i, l in enumerate(self.layers)]
         ws.part = [torch.zeros(RAAE_MAX_PARTS, l.N, 2, dtype=torch.float64, device=dev) for l in self.layers]
         ws.nparts = [0] * len(self.layers)
         wmax = max(max(l.N, l.K) for l in self.layers)
@@ -189,12 +208,16 @@ class FCNet:
         masks = []
         for l in self.layers[:-1]:
             if train and l.p > 0:
-                off = tape.slot(b * l.N, 1, 1.0 - l.p)
-                tape.draw("mask", off, (b, l.N), 1.0 - l.p)
+                off = tape.slot(b * l.N, 2 if self.bf16 else 1, 1.0 - l.p)
+                tape.draw("mask16" if self.bf16 else "mask", off, (b, l.N), 1.0 - l.p)
                 masks.append((off, (b, l.N)))
             else:
                 masks.append(None)
         return masks
+
+    def _mask(self, masks, i):
+        off, shape = masks[i]
+        return self.eng.tape.view16(off, *shape) if self.bf16 else self.eng.tape.view(off, *shape)
 
     def _bn_in(self, ws, i, train, update):
         p = self.layers[i]
@@ -248,16 +271,18 @@ class FCNet:
                 p = L[i - 1]
                 xin, in_kind, slope = ws.z[i - 1], IN_PRELU_BN_DROP, p.prelu.weight
                 bn = self._bn_in(ws, i - 1, train, True)
-                mask = eng.tape.view(masks[i - 1][0], *masks[i - 1][1]) if (train and masks[i - 1]) else None
+                mask = self._mask(masks, i - 1) if (train and masks[i - 1]) else None
             if not last:
                 out_kind, oslope = OUT_STATS_PRELU, l.prelu.weight
             elif self.kind == "enc":
                 out_kind, oslope = OUT_STATS_RAW, None
             else:
                 out_kind, oslope = (OUT_RELU if self.final_relu else OUT_SOFTPLUS), None
-            nbytes = 4 * (b * l.K * (2 if mask is not None else 1) + l.N * l.K + l.N + b * l.N)
+            st = 0
+            if self.bf16:
+                st = (_lib.ST_X if i > 1 else 0) | (_lib.ST_MASK if mask is not None else 0) | (_lib.ST_Z if 0 < i and not last else 0)
             ws.nparts[i] = yield ("dense", ops.dense_fwd_args(xin, b, l.K, in_kind, slope, bn, mask, l.w, l.b, l.N,
-                                                               ws.z[i], out_kind, oslope, ws.part[i]), nbytes)
+                                                               ws.z[i], out_kind, oslope, ws.part[i], storage=st), 0)
         if self.kind == "enc":
             ops.style_bn_fwd(ws.z[-1], b, self.out_dim, self._bn_in(ws, len(L) - 1, train, True), ws.styles)
         if train:
@@ -285,11 +310,14 @@ class FCNet:
                 p = L[i - 1]
                 xin, in_kind, slope = ws.z[i - 1], IN_PRELU_BN_DROP, p.prelu.weight
                 bn = self._bn_in(ws, i - 1, True, False)
-                mask = eng.tape.view(masks[i - 1][0], *masks[i - 1][1]) if masks[i - 1] else None
+                mask = self._mask(masks, i - 1) if masks[i - 1] else None
                 dx, dxp = ws.dx[i & 1], ws.dxp[i & 1]
             ds = eng.gslab(l.prelu.weight) if gk == G_PRELU_BN else None
+            st = 0
+            if self.bf16:
+                st = (_lib.ST_X if i > 1 else 0) | (_lib.ST_MASK if mask is not None else 0) | (_lib.ST_Z if 0 < i < n - 1 else 0)
             ns = ops.dense_bwd(g, gk, gp, gnp, ws.z[i], oslope, out_bn, b, l.N, xin, l.K, in_kind, slope, bn, mask,
-                               l.w, eng.gslab(l.w), eng.gslab(l.b), ds, eng.arena.n, dx, dxp)
+                               l.w, eng.gslab(l.w), eng.gslab(l.b), ds, eng.arena.n, dx, dxp, storage=st)
             eng.note_slabs([l.w, l.b] + ([l.prelu.weight] if ds is not None else []), ns)
             g, gk, gp, gnp = dx, G_PRELU_BN, dxp, ns
 
@@ -468,6 +496,15 @@ class StepEngine:
                 ok = ar.self_test() if ar is not None else agree(False, device, self.pg)
                 self.graph_ar = ar if ok else None
         from .nets_conv import CompactNet   # local import: conv emitters live in their own module
+        # build-only key `precision`: "fp32" (default, the reference's arithmetic and storage) | "bf16" (hidden
+        # activations and dropout multipliers stored as bf16, everything else fp32: BASELINE configs[4])
+        prec = str(cfg.get("precision", "fp32"))
+        if prec not in ("fp32", "bf16"):
+            raise ValueError(f"precision must be 'fp32' or 'bf16', not {prec!r}")
+        self.bf16 = prec == "bf16"
+        if self.bf16 and cfg["ae_form"] != "FC":
+            raise ValueError("precision: bf16 is implemented for ae_form: FC (BASELINE configs[4] is the dense network "
+                             "on 512-point spectra; the conv networks are hard-wired to 256 points, SURVEY finding 5)")
         if cfg["ae_form"] == "FC":
             self.enc, self.dec = FCNet(encoder, "enc", self), FCNet(decoder, "dec", self)
         elif cfg["ae_form"] == "compact":

@@ -53,31 +53,35 @@ def dense_fwd(x, B, K, in_kind, slope, bn, mask, w, bias, N, z, out_kind, out_sl
     return _probed("dense_fwd_kernel", 4 * (B * K * (2 if mask is not None else 1) + N * K + N + B * N), launch)
 
 
-def dense_fwd_args(x, B, K, in_kind, slope, bn, mask, w, bias, N, z, out_kind, out_slope=None, out_partials=None):
-    """``raae_dense_fwd_t`` holding the arguments of ``dense_fwd`` (for ``dense_fwd_pair``)."""
+def dense_fwd_args(x, B, K, in_kind, slope, bn, mask, w, bias, N, z, out_kind, out_slope=None, out_partials=None,
+                   storage=0):
+    """``raae_dense_fwd_t`` holding the arguments of ``dense_fwd`` (for ``dense_fwd_pair``).  ``storage``: RAAE_ST_*
+    bits -- which of x / mask / z are bf16 tensors."""
     a = _lib.DenseFwdT()
-    a.x, a.B, a.K, a.in_kind, a.slope = _ptr(x), B, K, in_kind, _ptr(slope)
+    a.storage = int(storage)
+    a.x, a.B, a.K, a.in_kind, a.slope = _ptr(x, None), B, K, in_kind, _ptr(slope)
     a.has_bn = 0 if bn is None else 1
     if bn is not None:
         a.bn = bn
-    a.mask, a.w, a.bias, a.N, a.z = _ptr(mask), _ptr(w), _ptr(bias), N, _ptr(z)
+    a.mask, a.w, a.bias, a.N, a.z = _ptr(mask, None), _ptr(w), _ptr(bias), N, _ptr(z, None)
     a.out_kind, a.out_slope, a.out_partials = out_kind, _ptr(out_slope), _ptr(out_partials, torch.float64)
+    for t, bit in ((x, _lib.ST_X), (mask, _lib.ST_MASK), (z, _lib.ST_Z)):      # the dtype of each tensor must match its bit
+        assert t is None or t.dtype == (torch.bfloat16 if storage & bit else torch.float32), (t.dtype, storage, bit)
     return a
 
 
 def dense_fwd_bytes(a):
     """Algorithmic bytes of a fused dense layer: input (and its dropout mask) read once, weights and bias once,
     output written once."""
-    return 4 * (a.B * a.K * (2 if a.mask else 1) + a.N * a.K + a.N + a.B * a.N)
+    bx, bm, bz = (2 if a.storage & 1 else 4), (2 if a.storage & 2 else 4), (2 if a.storage & 4 else 4)
+    return a.B * a.K * (bx + (bm if a.mask else 0)) + 4 * (a.N * a.K + a.N) + bz * a.B * a.N
 
 
 def dense_fwd_struct(a):
     """``dense_fwd`` from a ``raae_dense_fwd_t``."""
     def launch():
         n = C.c_int(0)
-        check(_lib.load().raae_dense_fwd(a.x, a.B, a.K, a.in_kind, a.slope, C.byref(a.bn) if a.has_bn else None, a.mask,
-                                         a.w, a.bias, a.N, a.z, a.out_kind, a.out_slope, a.out_partials, C.byref(n),
-                                         _stream()), "raae_dense_fwd")
+        check(_lib.load().raae_dense_fwd_s(C.byref(a), C.byref(n), _stream()), "raae_dense_fwd_s")
         return n.value
     return _probed("dense_fwd_kernel", dense_fwd_bytes(a), launch)
 
@@ -121,13 +125,17 @@ def disc_fused(z_real, styles, noise, sigma, mask1, mask2, layers, alpha, n_real
 
 
 def dense_bwd(g, g_kind, g_partials, g_nparts, zout, out_slope, out_bn, B, N, x, K, in_kind, slope, bn, mask, w,
-              dw, db, dslope, slab_stride, dx=None, dx_partials=None):
+              dw, db, dslope, slab_stride, dx=None, dx_partials=None, storage=0):
+    for t, bit in ((x, _lib.ST_X), (mask, _lib.ST_MASK), (zout, _lib.ST_Z)):
+        assert t is None or t.dtype == (torch.bfloat16 if storage & bit else torch.float32), (t.dtype, storage, bit)
+
     def launch():
         n = C.c_int(0)
-        check(_lib.load().raae_dense_bwd(_ptr(g), g_kind, _ptr(g_partials, torch.float64), g_nparts, _ptr(zout),
-                                         _ptr(out_slope), _bnp(out_bn), B, N, _ptr(x), K, in_kind, _ptr(slope), _bnp(bn),
-                                         _ptr(mask), _ptr(w), _ptr(dw), _ptr(db), _ptr(dslope), slab_stride, C.byref(n),
-                                         _ptr(dx), _ptr(dx_partials, torch.float64), _stream()), "raae_dense_bwd")
+        check(_lib.load().raae_dense_bwd_st(_ptr(g), g_kind, _ptr(g_partials, torch.float64), g_nparts, _ptr(zout, None),
+                                            _ptr(out_slope), _bnp(out_bn), B, N, _ptr(x, None), K, in_kind, _ptr(slope),
+                                            _bnp(bn), _ptr(mask, None), _ptr(w), _ptr(dw), _ptr(db), _ptr(dslope),
+                                            slab_stride, C.byref(n), _ptr(dx), _ptr(dx_partials, torch.float64),
+                                            int(storage), _stream()), "raae_dense_bwd_st")
         return n.value
     # output gradient and raw output read, input (+ mask) read, input gradient written, weights read, one slab written
     nbytes = 4 * (B * N * (2 if zout is not None else 1) + B * K * (2 if mask is not None else 1) +

@@ -608,3 +608,67 @@ def test_branched_graph_is_bitwise_eager_b4096(ae_form):
         assert results[0][1] == other[1]
         assert all(torch.equal(x, y) for x, y in zip(results[0][3], other[3]))
     assert all(np.isfinite(v) for v in results[0][1].values())
+
+
+def test_bf16_storage_mode_fc_512_aux12():
+    """BASELINE configs[4] (512-point spectra, 12 descriptors, nstyle 13, dense networks) with the build-only key
+    ``precision: bf16``: hidden activations and dropout multipliers are STORED as bf16, every product, sum,
+    BatchNorm statistic, gradient and Adam moment stays fp32 / double.  The reference arithmetic is fp32
+    (sc/clustering/dataloader.py:61) and the 1e-4 parity gate applies to the default fp32 mode only; for bf16 the
+    stated bound is: teacher-forced from the same state and random tape, every phase loss within 2e-2 relative of
+    the fp32 engine's (the rank loss, a cancelling sum: 5e-3 absolute) (bf16 keeps 8 significant bits, 4e-3 per element; five dense layers and a BatchNorm each way),
+    the phase gradients are REPORTED and only loosely bounded (relative L2 error <= 0.4).
+    Measured: rank phase 1.6 %, adversarial 12 %, smoothness 8 %, reconstruction / mutual information 20-25 %.  The
+    cause is the architecture, not the kernels: BatchNorm1d(affine=False) behind PReLU(0.01) normalises "dead" units
+    (all-negative pre-activations, batch std ~1e-4 after the slope) back to unit variance, so a bf16 step on the stored
+    pre-activation (2^-8 relative) comes out of the BatchNorm as O(0.1) noise; fp32 storage keeps 16 more bits there.
+    The first layer's output is kept fp32 for the same reason (its input, the raw spectrum, is not normalised: with
+    it in bf16 the errors were 40-70 %).  DESIGN.md section 7 says so: bf16 storage is offered because BASELINE
+    configs[4] names it, fp32 stays the default and the only mode the 1e-4 parity gate applies to.  The fp32 mode itself must not notice that the bf16 mode exists: two
+    fp32 engines from the same seed stay bit for bit equal, and an fp32 engine never passes a storage bit."""
+    g, cfg, spec, aux = load_case("fc_512_aux12")
+    bs = cfg["batch_size"]
+    runs = {}
+    for prec in ("fp32", "fp32", "bf16"):
+        torch.manual_seed(99)
+        eng = build_engine(dict(cfg, precision=prec, pair_unused_forwards=False), g["model_seed"], spec, aux)
+        assert eng.bf16 == (prec == "bf16")
+        assert all(z.dtype == (torch.bfloat16 if prec == "bf16" and 0 < i < 4 else torch.float32)
+                   for i, z in enumerate(eng.plan(bs).enc.z))
+        grads, losses = {}, []
+        eng.phase_hook = lambda name, P: grads.__setitem__(name, eng.phase_gradient(P, name).cpu())
+        state0 = eng.arena.P.clone()
+
+        def reset(name, P):          # teacher forcing: every phase starts from the initial weights
+            eng.arena.P.copy_(state0)
+        eng.post_phase_hook = reset
+        torch.manual_seed(5)         # the host tape: same draws for every run
+        eng.set_epoch(torch.arange(len(eng.train_spec)), 0.3)
+        eng.step(bs)
+        runs.setdefault(prec, []).append((eng.losses(), grads))
+    a, b = runs["fp32"]
+    assert a[0] == b[0] and all(torch.equal(a[1][k], b[1][k]) for k in a[1]), "fp32 mode is not reproducible bit for bit"
+    (l16, g16), (l32, g32) = runs["bf16"][0], a
+    assert l16 != l32, "bf16 storage changed nothing: the mode is not active"
+    for k in KEYS:
+        # (the rank loss is a signed sum of O(0.5) pair products that nearly cancel -- 0.024 here: its bound is absolute,
+        # the 4e-3 a bf16-rounded style moves each product by)
+        tol = 5e-3 if k == "kendall" else 2e-2 * abs(l32[k]) + 1e-6
+        assert abs(l16[k] - l32[k]) <= tol, (k, l16[k], l32[k])
+    report = {}
+    for name in g32:
+        err, scale = float((g16[name] - g32[name]).abs().max()), float(g32[name].abs().max())
+        l2 = float((g16[name] - g32[name]).norm() / g32[name].norm())
+        report[name] = (round(err / scale, 4), round(l2, 4))
+    print("\nbf16 vs fp32 phase gradients (max error / |g|inf, relative L2 error):", report)
+    for name, (emax, el2) in report.items():
+        assert el2 <= 0.4 and emax <= 0.45, (name, emax, el2)
+    print("\nbf16 vs fp32 losses:", {k: (round(l16[k], 6), round(l32[k], 6)) for k in KEYS})
+    # free-running smoke: hipGraph replay with the device tape, finite losses after 6 steps
+    eng = build_engine(dict(cfg, precision="bf16"), g["model_seed"], spec, aux, use_graph=True, rng_mode="philox")
+    eng.set_epoch(torch.arange(len(eng.train_spec)), 0.3)
+    for _ in range(3):
+        eng.step(bs)
+    assert all(np.isfinite(v) for v in eng.losses().values())
+    with pytest.raises(ValueError, match="precision: bf16"):
+        build_engine(dict(load_case("compact_small")[1], precision="bf16"), 1, *load_case("compact_small")[2:])
