@@ -103,8 +103,10 @@ __device__ __forceinline__ void stage_rows(float* Xs, int pitch, const float* x,
 // stay in registers (KQ floats per lane = the B operands of all K/4 MFMA steps) across its row tiles.
 // (bx, by) of a (gx, *) grid: the workgroup's tile / column-block index (the whole grid of dense_fwd_kernel, one of
 // the two ranges of dense_fwd2_kernel)
-template <int KQ>
+// ST: instance that honours a.storage (bf16 storage); the fp32 instances (ST false) carry none of its branches
+template <int KQ, bool ST = false>
 __device__ __forceinline__ void dense_fwd_body(const DenseFwdArgs& a, const int bx, const int by, const int gx, float* smem) {
+    const int st = ST ? a.storage : 0;
     const int K4 = (a.K + 3) & ~3;
     float* s_mean = smem;
     float* s_rstd = s_mean + K4;
@@ -139,7 +141,7 @@ __device__ __forceinline__ void dense_fwd_body(const DenseFwdArgs& a, const int 
 
     for (int tile = bx; tile < ntiles; tile += gx) {
         const int row0 = tile << 4;
-        stage_rows(Xs, a.pitch, a.x, a.mask, row0, a.B, a.K, K4, a.in_kind, s_slope, s_mean, s_rstd, a.storage);
+        stage_rows(Xs, a.pitch, a.x, a.mask, row0, a.B, a.K, K4, a.in_kind, s_slope, s_mean, s_rstd, st);
         __syncthreads();
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -153,11 +155,11 @@ __device__ __forceinline__ void dense_fwd_body(const DenseFwdArgs& a, const int 
                 const int row = row0 + (lane >> 4) * 4 + j;
                 if (row < a.B) {
                     float zv = acc[j] + bias;
-                    if (a.storage & RAAE_ST_Z) zv = bf16_round(zv);
+                    if (st & RAAE_ST_Z) zv = bf16_round(zv);
                     float o = zv;
                     if (a.out_kind == RAAE_OUT_SOFTPLUS) o = raae::softplus2(zv);
                     else if (a.out_kind == RAAE_OUT_RELU) o = fmaxf(zv, 0.f);
-                    if (a.storage & RAAE_ST_Z) bf16_store(a.z, (size_t)row * a.N + col, o);
+                    if (st & RAAE_ST_Z) bf16_store(a.z, (size_t)row * a.N + col, o);
                     else a.z[(size_t)row * a.N + col] = o;
                     if (a.out_kind == RAAE_OUT_STATS_PRELU || a.out_kind == RAAE_OUT_STATS_RAW) {
                         const float v = (a.out_kind == RAAE_OUT_STATS_PRELU) ? prelu(zv, oslope) : zv;
@@ -178,10 +180,10 @@ __device__ __forceinline__ void dense_fwd_body(const DenseFwdArgs& a, const int 
     }
 }
 
-template <int KQ>
+template <int KQ, bool ST = false>
 __global__ __launch_bounds__(256) void dense_fwd_kernel(DenseFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    dense_fwd_body<KQ>(a, blockIdx.x, blockIdx.y, gridDim.x, smem);
+    dense_fwd_body<KQ, ST>(a, blockIdx.x, blockIdx.y, gridDim.x, smem);
 }
 
 // Two independent layers (one of the encoder, one of the decoder: the forward chain whose result the reference
@@ -210,9 +212,10 @@ struct DenseBwdArgs {
 // TPW: 16x16 dW tiles per wave; KT4: 16-column dx tiles per wave.
 // LDS: o_mean[N16] o_rstd[N16] o_slope[N16] m1[N16] m2[N16] | i_mean[K16] i_rstd[K16] i_slope[K16]
 //      | Gs[16][pitch_g] | Xs[16][pitch_x] | red[2][256]
-template <int TPW, int KT4>
+template <int TPW, int KT4, bool ST = false>
 __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int st = ST ? a.storage : 0;
     const int N16 = (a.N + 15) & ~15, K16 = (a.K + 15) & ~15;
     float* o_mean = smem;
     float* o_rstd = o_mean + N16;
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
     const int grstep = wideN ? 1 : 4;
     double db_acc[2] = {0.0, 0.0}, ds_acc[2] = {0.0, 0.0};
 
-    const bool zb = (a.storage & RAAE_ST_Z) != 0;
+    const bool zb = (st & RAAE_ST_Z) != 0;
     const int ntiles = (a.B + 15) >> 4;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile << 4;
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
             }
         }
         // ---- 2. layer input tile -> Xs (transform applied) ----
-        stage_rows(Xs, a.pitch_x, a.x, a.mask, row0, a.B, a.K, K16, a.in_kind, i_slope, i_mean, i_rstd, a.storage);
+        stage_rows(Xs, a.pitch_x, a.x, a.mask, row0, a.B, a.K, K16, a.in_kind, i_slope, i_mean, i_rstd, st);
         __syncthreads();
         // ---- 3. dW[n][k] += sum_rows dz[row][n] * xin[row][k]; wave owns tiles t = wv + 4 i ----
 #pragma unroll
@@ -354,10 +357,10 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
                             if (row < a.B) {
                                 const size_t o = (size_t)row * a.K + kcol;
                                 float d = acc[j];
-                                if (a.in_kind != RAAE_IN_NONE && a.mask) d *= (a.storage & RAAE_ST_MASK) ? bf16_at(a.mask, o) : a.mask[o];
+                                if (a.in_kind != RAAE_IN_NONE && a.mask) d *= (st & RAAE_ST_MASK) ? bf16_at(a.mask, o) : a.mask[o];
                                 a.dx[o] = d;
                                 if (a.dx_partials != nullptr) {
-                                    const float xv = (a.storage & RAAE_ST_X) ? bf16_at(a.x, o) : a.x[o];
+                                    const float xv = (st & RAAE_ST_X) ? bf16_at(a.x, o) : a.x[o];
                                     const float y = (prelu(xv, i_slope[kcol]) - i_mean[kcol]) * i_rstd[kcol];
                                     dxs[i] += (double)d;
                                     dxq[i] += (double)d * (double)y;
@@ -454,6 +457,13 @@ static int prep_dense_fwd(const float* x, int B, int K, int in_kind, const float
 }
 
 static void launch_dense_fwd(const DenseFwdArgs& a, dim3 grid, size_t lds, int kq, hipStream_t st) {
+    if (a.storage) {        // bf16 storage: the hidden layers of the dense networks (K <= 64 -> KQ 16; first layer KQ 64 / 128)
+        if (kq == 4) hipLaunchKernelGGL((dense_fwd_kernel<4, true>), grid, dim3(256), lds, st, a);
+        else if (kq == 16) hipLaunchKernelGGL((dense_fwd_kernel<16, true>), grid, dim3(256), lds, st, a);
+        else if (kq == 64) hipLaunchKernelGGL((dense_fwd_kernel<64, true>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((dense_fwd_kernel<128, true>), grid, dim3(256), lds, st, a);
+        return;
+    }
     if (kq == 4) hipLaunchKernelGGL(dense_fwd_kernel<4>, grid, dim3(256), lds, st, a);
     else if (kq == 16) hipLaunchKernelGGL(dense_fwd_kernel<16>, grid, dim3(256), lds, st, a);
     else if (kq == 64) hipLaunchKernelGGL(dense_fwd_kernel<64>, grid, dim3(256), lds, st, a);
@@ -514,8 +524,8 @@ extern "C" int raae_dense_fwd2(const raae_dense_fwd_t* p, const raae_dense_fwd_t
     const size_t lds = l1 > l2 ? l1 : l2;
     // instances: the layer pairs of the 256-point dense networks (first layers 256 -> 64 beside 6 -> 64, then 64-wide
     // layers beside each other); anything else: two launches
-    if (q1 == 64 && q2 == 4) hipLaunchKernelGGL((dense_fwd2_kernel<64, 4>), grid, dim3(256), lds, st, k);
-    else if (q1 == 16 && q2 == 16) hipLaunchKernelGGL((dense_fwd2_kernel<16, 16>), grid, dim3(256), lds, st, k);
+    if (!(p->storage | q->storage) && q1 == 64 && q2 == 4) hipLaunchKernelGGL((dense_fwd2_kernel<64, 4>), grid, dim3(256), lds, st, k);
+    else if (!(p->storage | q->storage) && q1 == 16 && q2 == 16) hipLaunchKernelGGL((dense_fwd2_kernel<16, 16>), grid, dim3(256), lds, st, k);
     else {
         launch_dense_fwd(k.x, g1, l1, q1, st);
         launch_dense_fwd(k.y, g2, l2, q2, st);
@@ -572,7 +582,8 @@ extern "C" int raae_dense_bwd_st(const float* g, int g_kind, const double* g_par
     dim3 grid(gx), block(256);
     hipStream_t st = (hipStream_t)stream;
     const bool need_dx = dx != nullptr;
-#define RAAE_BWD(TPW_, KT4_) hipLaunchKernelGGL((dense_bwd_kernel<TPW_, KT4_>), grid, block, lds, st, a)
+#define RAAE_BWD(TPW_, KT4_) do { if (storage) hipLaunchKernelGGL((dense_bwd_kernel<TPW_, KT4_, true>), grid, block, lds, st, a); \
+                                 else hipLaunchKernelGGL((dense_bwd_kernel<TPW_, KT4_, false>), grid, block, lds, st, a); } while (0)
     if (tpw <= 1 && kt4 <= 1) RAAE_BWD(1, 1);
     else if (tpw <= 4 && kt4 <= 1) RAAE_BWD(4, 1);
     else if (tpw <= 16 && (kt4 <= 1 || !need_dx)) RAAE_BWD(16, 1);
