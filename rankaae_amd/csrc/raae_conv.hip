@@ -506,6 +506,14 @@ int pick_S(long floats_per_sample, long outputs_per_sample, int B, long lds_budg
     // large batches: about two groups per workgroup of a 512-workgroup grid, up to 4x the samples per group
     // (fewer barriers, more loads in flight per staging pass; measured at B = 4096: 180 -> 201 steps/s, 8x: 192)
     long want = (B + 1023) / 1024;
+    // small samples (a few KB per sample): ONE group per workgroup of the 512-workgroup grid -- such kernels are a chain
+    // of barrier-separated stages of a few microseconds each, and a second group repeats the chain
+    // (measured at B = 4096: 217 -> 223 steps/s with the threshold anywhere between 1400 and 4400 floats per sample)
+    static const long small_floats = getenv("RAAE_PICK_SMALL") ? atol(getenv("RAAE_PICK_SMALL")) : 2200;
+    static const long small_mult = getenv("RAAE_PICK_MULT") ? atol(getenv("RAAE_PICK_MULT")) : 8;
+    if (floats_per_sample <= small_floats) want = (B + 511) / 512;
+    if (want > small_mult * S && floats_per_sample <= small_floats) want = small_mult * S;
+    else
     if (want > 4 * S) want = 4 * S;
     if (S < want) S = want;
     if (S > cap) S = cap;
@@ -970,7 +978,11 @@ extern "C" int raae_block_bwd_a(const raae_block_bwd_a_t* in, int* nparts, void*
 }
 
 // workgroups per weight-gradient task (= slabs it writes); 64 -> 128: +2 % at B=256, +18 % at B=4096
-static const int kWgradTaskGrid = 128;
+static const int kWgradTaskGridDefault = 128;
+// tuning knobs (environment, read once): RAAE_WGRAD_GRID workgroups per task, RAAE_WGRAD_S samples per group (0: automatic)
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static const int kWgradTaskGrid = env_int("RAAE_WGRAD_GRID", kWgradTaskGridDefault);
+static const int kWgradForceS = env_int("RAAE_WGRAD_S", 0);
 // checks + task table + launch geometry of a block's weight-gradient tasks; `m` is filled
 static int prep_block_wgrad(const raae_block_wgrad_t* in, int* nslab, WgradMultiArgs& m, int& total_out, size_t& dyn_out,
                             int& kind_out) {
@@ -991,6 +1003,7 @@ static int prep_block_wgrad(const raae_block_wgrad_t* in, int* nslab, WgradMulti
         RAAE_CHECK_ARG(t.a.nw <= 1024 && per <= kTileBudget);
         t.slab_stride = in->slab_stride; t.sh_in = lg2(cv->Lin); t.sh_out = lg2(cv->Lout);
         t.S = pick_S(per, cv->transposed ? cv->Lin : cv->Lout, in->B, kTileBudget, 256);
+        if (kWgradForceS > 0 && in->B >= RAAE_BIG_ROWS) { t.S = kWgradForceS; const long cap = (36 * 1024) / per; if (t.S > cap) t.S = (int)cap; if (t.S < 1) t.S = 1; }
         { const int scap = (in->B + kWgradTaskGrid - 1) / kWgradTaskGrid; if (t.S > scap) t.S = scap; }   // parallelism from workgroups, not from samples per group
         t.ngroups = (in->B + t.S - 1) / t.S;
         const int grid = t.ngroups < kWgradTaskGrid ? t.ngroups : kWgradTaskGrid;
@@ -1010,6 +1023,7 @@ static int prep_block_wgrad(const raae_block_wgrad_t* in, int* nslab, WgradMulti
         RAAE_CHECK_ARG(per <= kTileBudget);
         t.slab_stride = in->slab_stride; t.sh_in = lg2(c.Lin); t.sh_e = lg2(c.E);
         t.S = pick_S(per, c.C, in->B, kTileBudget, 64);
+        if (kWgradForceS > 0 && in->B >= RAAE_BIG_ROWS) { t.S = kWgradForceS; const long cap = (36 * 1024) / per; if (t.S > cap) t.S = (int)cap; if (t.S < 1) t.S = 1; }
         { const int scap = (in->B + kWgradTaskGrid - 1) / kWgradTaskGrid; if (t.S > scap) t.S = scap; }   // parallelism from workgroups, not from samples per group
         t.ngroups = (in->B + t.S - 1) / t.S;
         const int grid = t.ngroups < kWgradTaskGrid ? t.ngroups : kWgradTaskGrid;

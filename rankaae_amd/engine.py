@@ -611,13 +611,21 @@ class StepEngine:
         torch.cuda.current_stream().wait_event(ev)
         self._events.append(ev)
 
-    def join_side_streams(self):
+    def join_side_streams(self, keep=0):
+        """The current stream waits for the side streams; ``keep`` > 0 leaves the ``keep`` most recently forked ones
+        running (the side streams are used round-robin, so those are the last ``keep`` of the rotation)."""
+        recent = set()
+        if keep > 0 and self.side_streams:
+            n = len(self.side_streams)
+            recent = {self.side_streams[(self._side_i - 1 - j) % n] for j in range(min(keep, n - 1))}
         for s in list(self._side_used):
+            if s in recent:
+                continue
             ev = torch.cuda.Event()
             ev.record(s)
             torch.cuda.current_stream().wait_event(ev)
             self._events.append(ev)
-        self._side_used.clear()
+            self._side_used.discard(s)
         if self._capture is None and len(self._events) > 4096:
             self._events.clear()
 

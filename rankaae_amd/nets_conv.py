@@ -367,7 +367,9 @@ class CompactNet:
                     [(g_, c_, e_, l_, v_, G_(mod.weight), G_(mod.bias)) for g_, c_, e_, l_, v_, mod in lins],
                     eng.arena.n)
                 if eng._branch:
-                    eng.join_side_streams()
+                    # `wgrad_overlap_depth` blocks' weight-gradient launches may be in flight at once (default 1: the
+                    # previous block's are joined before this one forks)
+                    eng.join_side_streams(keep=int(eng.cfg.get("wgrad_overlap_depth", 1)) - 1)
                     with eng.side_stream():
                         ns = ops.block_wgrad(b, None, None, eng.arena.n, args=wargs)
                     note_wgrad((wargs, convs, lins), ns)

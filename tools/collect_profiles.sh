@@ -1,0 +1,26 @@
+#!/bin/bash
+# Everything under profiles/ for one round, in one gpurun call:  gpurun --timeout 1150 -- 'bash tools/collect_profiles.sh r2'
+# (kernel-trace statistics, FETCH_SIZE / WRITE_SIZE in separate --pmc passes, one MFMA counter pass, bench lines)
+R=${1:-r2}
+set -x
+bash tools/profile.sh ${R}_compact_b256 --steps 200 --warmup 20 > /dev/null
+bash tools/profile.sh ${R}_compact_b4096 --batch 4096 --rows 100000 --steps 30 --warmup 5 > /dev/null
+bash tools/profile.sh ${R}_fc_b256 --ae-form FC --steps 200 --warmup 20 > /dev/null
+bash tools/profile.sh ${R}_fc_b4096 --ae-form FC --batch 4096 --rows 100000 --steps 30 --warmup 5 > /dev/null
+for wl in "compact_b256 --steps 20 --warmup 4" "compact_b4096 --batch 4096 --rows 100000 --steps 6 --warmup 3" "fc_b4096 --ae-form FC --batch 4096 --rows 100000 --steps 6 --warmup 3"; do
+  set -- $wl; name=$1; shift
+  bash tools/pmc.sh ${R}_pmc_fetch_$name "FETCH_SIZE" "$@" > /dev/null
+  bash tools/pmc.sh ${R}_pmc_write_$name "WRITE_SIZE" "$@" > /dev/null
+  python3 tools/pmc_summary.py traffic gpurun_out/${R}_pmc_fetch_$name.db gpurun_out/${R}_pmc_write_$name.db gpurun_out/${R}_pmc_traffic_$name.json "$*"
+  rm -f gpurun_out/${R}_pmc_fetch_$name.db gpurun_out/${R}_pmc_write_$name.db
+done
+bash tools/pmc.sh ${R}_pmc_mfma_fc_b4096 "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU" --ae-form FC --batch 4096 --rows 100000 --steps 6 --warmup 3 > /dev/null
+python3 tools/pmc_summary.py counters gpurun_out/${R}_pmc_mfma_fc_b4096.db gpurun_out/${R}_pmc_mfma_fc_b4096.json "--ae-form FC --batch 4096 --rows 100000 --steps 6 --warmup 3"
+rm -f gpurun_out/${R}_pmc_mfma_fc_b4096.db
+bash tools/pmc.sh ${R}_pmc_mfma_compact_b4096 "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU" --batch 4096 --rows 100000 --steps 6 --warmup 3 > /dev/null
+python3 tools/pmc_summary.py counters gpurun_out/${R}_pmc_mfma_compact_b4096.db gpurun_out/${R}_pmc_mfma_compact_b4096.json "--batch 4096 --rows 100000 --steps 6 --warmup 3"
+rm -f gpurun_out/${R}_pmc_mfma_compact_b4096.db
+python3 bench.py > gpurun_out/${R}_bench_compact.log 2>&1; grep '^{' gpurun_out/${R}_bench_compact.log > gpurun_out/${R}_bench_compact.json
+python3 bench.py --ae-form FC > gpurun_out/${R}_bench_fc.log 2>&1; grep '^{' gpurun_out/${R}_bench_fc.log > gpurun_out/${R}_bench_fc.json
+python3 tools/rank_scale.py > gpurun_out/${R}_rank_scale.log 2>&1
+ls -la gpurun_out/${R}_*
