@@ -182,7 +182,7 @@ def configs2_line(args, cfg0, dev):
     for _ in range(4):
         one_step()
     torch.cuda.synchronize()
-    steps = 40
+    steps = 80
     t0 = time.perf_counter()
     for _ in range(steps):
         one_step()

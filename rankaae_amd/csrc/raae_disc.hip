@@ -287,12 +287,15 @@ __global__ __launch_bounds__(256) void disc_fused_kernel(DiscArgs a) {
         s_last = atomicAdd(a.ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
     }
     __syncthreads();
-    if (s_last && t == 0) {
+    if (s_last) {                             // uniform per workgroup: all its threads add the partials (fixed-order tree)
         __threadfence();
         double sum = 0.0;
-        for (unsigned i = 0; i < gridDim.x; ++i) sum += ((volatile double*)a.partial)[i];
-        a.loss[0] = (float)sum;
-        *a.ticket = 0u;
+        for (unsigned i = t; i < gridDim.x; i += 256) sum += ((volatile double*)a.partial)[i];
+        sum = raae::block_sum(sum, shd);
+        if (t == 0) {
+            a.loss[0] = (float)sum;
+            *a.ticket = 0u;
+        }
     }
 }
 

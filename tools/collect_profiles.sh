@@ -20,6 +20,7 @@ rm -f gpurun_out/${R}_pmc_mfma_fc_b4096.db
 bash tools/pmc.sh ${R}_pmc_mfma_compact_b4096 "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU" --batch 4096 --rows 100000 --steps 6 --warmup 3 > /dev/null
 python3 tools/pmc_summary.py counters gpurun_out/${R}_pmc_mfma_compact_b4096.db gpurun_out/${R}_pmc_mfma_compact_b4096.json "--batch 4096 --rows 100000 --steps 6 --warmup 3"
 rm -f gpurun_out/${R}_pmc_mfma_compact_b4096.db
+mkdir -p profiles; cp gpurun_out/${R}_pmc_traffic_*.json profiles/      # bench.py reads roofline.traffic from them
 python3 bench.py > gpurun_out/${R}_bench_compact.log 2>&1; grep '^{' gpurun_out/${R}_bench_compact.log > gpurun_out/${R}_bench_compact.json
 python3 bench.py --ae-form FC > gpurun_out/${R}_bench_fc.log 2>&1; grep '^{' gpurun_out/${R}_bench_fc.log > gpurun_out/${R}_bench_fc.json
 python3 tools/rank_scale.py > gpurun_out/${R}_rank_scale.log 2>&1

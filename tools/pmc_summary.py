@@ -21,12 +21,17 @@ def norm(name):
 
 
 def per_kernel(path):
-    """``{kernel: {counter: (launches, mean value)}}``"""
+    """``{kernel: {counter: (launches, mean value per launch)}}`` -- a raw counter has one record per hardware instance
+    (XCD / shader engine) of a dispatch: they are summed per dispatch first.  ``"_duration_ns"`` is added per kernel."""
     db = sqlite3.connect(path)
     out = {}
-    for name, ctr, n, mean in db.execute("select name, counter_name, count(*), avg(counter_value) from pmc_events "
-                                         "group by name, counter_name"):
-        out.setdefault(norm(name), {})[ctr] = (n, mean)
+    q = ("select name, counter_name, count(*), avg(v), avg(d) from (select name, counter_name, dispatch_id, "
+         "sum(counter_value) as v, max(duration) as d from pmc_events group by name, counter_name, dispatch_id) "
+         "group by name, counter_name")
+    for name, ctr, n, mean, dur in db.execute(q):
+        k = out.setdefault(norm(name), {})
+        k[ctr] = (n, mean)
+        k["_duration_ns"] = (n, dur)
     return out
 
 
@@ -35,6 +40,7 @@ def traffic(fetch_db, write_db, out, note=""):
     kernels = {}
     for k in sorted(set(f) | set(w)):
         n, fk = f.get(k, {}).get("FETCH_SIZE", (0, 0.0))
+        n = n or w.get(k, {}).get("WRITE_SIZE", (0, 0.0))[0]
         _, wk = w.get(k, {}).get("WRITE_SIZE", (0, 0.0))
         kernels[k] = {"launches": n, "fetch_kb": round(fk, 1), "write_kb": round(wk, 1),
                       "hbm_bytes_raw": int((fk + wk) * 1024), "hbm_bytes_fetch_doubled": int((2 * fk + wk) * 1024)}
@@ -67,11 +73,16 @@ def counters(path, out, note=""):
     for name, c in k.items():
         row = {"launches": max(n for n, _ in c.values())}
         row.update({ctr: round(v, 1) for ctr, (_, v) in c.items()})
-        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and c.get("SQ_BUSY_CYCLES", (0, 0))[1] > 0:
-            row["mfma_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"][1] / c["SQ_BUSY_CYCLES"][1], 4)
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and c["_duration_ns"][1] > 0:
+            # matrix-core utilisation: busy cycles summed over the chip / (kernel duration x SIMDs x clock).  The
+            # clock is the nominal 2.4 GHz (DVFS lowers it under load: the true utilisation is a little higher)
+            row["mfma_util_at_2.4GHz"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"][1] / (c["_duration_ns"][1] * 2.4 * 1024), 4)
+            if c.get("SQ_INSTS_VALU", (0, 0))[1] > 0 and "SQ_INSTS_VALU_MFMA_MOPS_F32" in c:
+                row["mfma_ops_per_valu_inst"] = round(c["SQ_INSTS_VALU_MFMA_MOPS_F32"][1] / c["SQ_INSTS_VALU"][1], 4)
         res[name] = row
     json.dump({"command": "rocprofv3 --kernel-trace --pmc <counters> (tools/pmc.sh) -- python3 bench.py ... " + note,
-               "unit": "counter value per launch, averaged over the launches of a kernel",
+               "unit": "counter value per launch (summed over the hardware instances of a dispatch), averaged over the "
+                       "launches of a kernel; SQ_VALU_MFMA_BUSY_CYCLES = 8 cycles per v_mfma_f32_16x16x4_f32",
                "kernels": res}, open(out, "w"), indent=1)
 
 
