@@ -6,8 +6,9 @@ engine.  The ipyparallel engine farm (``train_sc.py:19-45``) becomes one worker 
 trial ``k`` runs on worker ``k mod n`` and worker ``w`` uses GPU ``w mod ngpus`` (``RANKAAE_TRIAL_WORKERS``
 overrides ``n``; the config key ``trials_per_gpu`` puts several workers on each GPU, which scales to ~2.8x at 4 --
 DESIGN.md section 8).  When launched under
-``torch.distributed.run`` (WORLD_SIZE > 1) every trial instead trains data-parallel over RCCL
-(``rankaae_amd.parallel``)."""
+``torch.distributed.run`` (WORLD_SIZE > 1) every trial instead trains data-parallel over RCCL: all ranks run the trials
+one after the other, each trial is ONE training run (``Trainer`` shards every global batch over the ranks and averages
+the gradients, rankaae_amd/trainer.py), and rank 0 alone writes the logs, checkpoints and ``final.pt``."""
 import argparse
 import logging
 import os
@@ -30,8 +31,11 @@ def run_training(job_number, work_dir, train_config, verbose, data_file, timeout
                  logger=logging.getLogger("training")):
     work_dir = f"{work_dir}/training/job_{job_number + 1}"
     os.makedirs(work_dir, exist_ok=True)
-    logger = create_logger(f"subtraining_{job_number + 1}", os.path.join(work_dir, "messages.txt"))
-    loss_logger = create_logger(f"losses_{job_number + 1}", os.path.join(work_dir, "losses.csv"), simple_fmt=True)
+    if _is_lead_rank():
+        logger = create_logger(f"subtraining_{job_number + 1}", os.path.join(work_dir, "messages.txt"))
+        loss_logger = create_logger(f"losses_{job_number + 1}", os.path.join(work_dir, "losses.csv"), simple_fmt=True)
+    else:       # data parallel: the trial is ONE training run on all ranks, rank 0 alone keeps the logs and files
+        logger = loss_logger = _null_logger()
     ngpus = torch.cuda.device_count()
     local_id = int(os.environ.get("LOCAL_RANK", os.environ.get("SLURM_LOCALID", 0)))
     igpu = local_id % ngpus if ngpus > 0 else -1
@@ -47,6 +51,18 @@ def run_training(job_number, work_dir, train_config, verbose, data_file, timeout
     time_used = time.time() - start
     logger.info(f"Training finished. Time used: {time_used:.2f}s.\n\n")
     return metrics, time_used
+
+
+def _is_lead_rank():
+    return int(os.environ.get("WORLD_SIZE", "1")) == 1 or int(os.environ.get("RANK", "0")) == 0
+
+
+def _null_logger():
+    lg = logging.getLogger("rankaae_amd.null")
+    if not lg.handlers:
+        lg.addHandler(logging.NullHandler())
+    lg.propagate = False
+    return lg
 
 
 def assign_trials(trials, nworkers):
@@ -97,7 +113,8 @@ def main():
     trials = train_config.get("trials", 1)
     data_file = os.path.join(work_dir, train_config.get("data_file", None))
     timeout = train_config.get("timeout", 10)
-    logger = create_logger("Main training:", f"{work_dir}/main_process_message.txt", append=True)
+    logger = create_logger("Main training:", f"{work_dir}/main_process_message.txt", append=True) if _is_lead_rank() \
+        else _null_logger()
     logger.info("START")
     start = time.time()
     result, nworkers = run_trials(trials, work_dir, train_config, verbose, data_file, timeout, logger)

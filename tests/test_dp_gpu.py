@@ -254,3 +254,41 @@ def test_trainer_data_parallel_two_ranks(tmp_path):
     mp.spawn(_trainer_dp_worker, args=(2, _free_port(), str(tmp_path), "compact_small"), nprocs=2, join=True)
     model = torch.load(os.path.join(str(tmp_path), "final.pt"), map_location="cpu", weights_only=False)
     assert set(model) == {"Encoder", "Decoder", "Style Discriminator"}
+
+
+def test_train_sc_under_torch_distributed_run(tmp_path):
+    """The documented multi-GPU command: ``python -m torch.distributed.run --nproc-per-node 2 -m
+    rankaae_amd.cmd.train_sc -c cfg.yaml -w dir`` -- here two ranks on the one GPU over gloo (RANKAAE_DP_BACKEND).
+    Each trial is ONE data-parallel training run: one job directory per trial with ONE set of log lines and files,
+    written by rank 0 (before, every rank trained every trial on its own and raced on the files)."""
+    import json
+    import subprocess
+    import sys
+    import yaml
+    from rankaae_amd.synthetic import make_spectra, write_csv
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", "ref_fc_small.json")) as f:
+        g = json.load(f)
+    cfg = dict(g["config"])
+    cfg.update(max_epoch=11, trials=2, data_file="data.csv", verbose=False, timeout=1, batch_size=32)
+    spec, aux, grid = make_spectra(g["n_rows"], g["n_points"], cfg["n_aux"], seed=g["data_seed"])
+    write_csv(str(tmp_path / "data.csv"), spec, aux, grid)
+    with open(tmp_path / "cfg.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    env = dict(os.environ, PYTHONPATH=root, RANKAAE_DP_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "-m", "rankaae_amd.cmd.train_sc",
+                        "-c", "cfg.yaml", "-w", str(tmp_path)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    main_log = (tmp_path / "main_process_message.txt").read_text()
+    assert main_log.count("START") == 1 and main_log.count("END") == 1 and "Running with 2 process(es)." in main_log
+    for k in (1, 2):
+        job = tmp_path / "training" / f"job_{k}"
+        msgs = (job / "messages.txt").read_text()
+        assert msgs.count("Training started") == 1 and msgs.count("Training finished") == 1
+        rows = [ln for ln in (job / "losses.csv").read_text().splitlines() if ln.strip()]
+        assert rows[0].startswith("Epoch,Train_D") and [ln.split(",")[0] for ln in rows[1:]] == ["0", "10"], rows
+        model = torch.load(job / "final.pt", map_location="cpu", weights_only=False)
+        assert set(model) == {"Encoder", "Decoder", "Style Discriminator"}
