@@ -669,6 +669,21 @@ class StepEngine:
         self._cursor_primed = False
         self._host_cursor = int(start)
 
+    @_on_stream
+    def average_over_ranks(self, tensors):
+        """In-place mean over the ranks of a list of small device tensors (BatchNorm running statistics before a
+        validation pass).  The collective runs on the dedicated communication stream like every torch.distributed
+        call of the engine: RCCL's work events must not be recorded on the engine's own stream, which captures
+        hipGraphs (the process-group watchdog polls them with hipEventQuery)."""
+        if self.world_size == 1 or not tensors:
+            return
+        flat = torch.cat([t.reshape(-1).float() for t in tensors])
+        self._run_comm("mean", (flat,))
+        off = 0
+        for t in tensors:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+
     def close(self):
         """Release the private RCCL communicator (data-parallel runs)."""
         if self.graph_ar is not None:

@@ -75,17 +75,3 @@ def broadcast_tensor_from_rank0(t, device, group=None):
     buf = t.to(device) if dist.get_backend(group) == "nccl" else t.clone()
     dist.broadcast(buf, src=0, group=group)
     return buf.cpu()
-
-
-def average_(tensors, group=None):
-    """In-place mean over ranks of a list of small tensors (BatchNorm running statistics at the end of an epoch: the
-    replicas keep per-replica statistics, DDP semantics, and meet before validation so that every rank validates --
-    and schedules its learning rates -- on the same numbers)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1 or not tensors:
-        return
-    flat = torch.cat([t.reshape(-1).float() for t in tensors])
-    allreduce_mean_(flat, group)
-    off = 0
-    for t in tensors:
-        t.copy_(flat[off:off + t.numel()].view_as(t))
-        off += t.numel()

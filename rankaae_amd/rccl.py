@@ -125,6 +125,25 @@ class GraphAllReduce:
                     g.launch()
                 side.synchronize()
                 ok = ok and bool(torch.allclose(y, torch.full_like(y, want)))
+                # the two collectives of the global-pairs rank loss: all-gather (fp32) and sum (fp64), eager + captured
+                src = torch.full((16,), float(self.rank + 1), device=self.device)
+                dst = torch.zeros(16 * self.world, device=self.device)
+                tot = torch.full((8,), float(self.rank + 1), dtype=torch.float64, device=self.device)
+                self.gather_(src, dst)
+                self.sum_(tot)
+                side.synchronize()
+                want_g = torch.arange(1, self.world + 1, device=self.device, dtype=torch.float32).repeat_interleave(16)
+                ok = ok and bool(torch.equal(dst, want_g)) and bool(torch.allclose(tot, torch.full_like(tot, self.world * (self.world + 1) / 2.0)))
+                g2 = ops.Graph()
+                g2.begin()
+                dst.zero_()
+                tot.fill_(float(self.rank + 1))
+                self.gather_(src, dst)
+                self.sum_(tot)
+                g2.end()
+                g2.launch()
+                side.synchronize()
+                ok = ok and bool(torch.equal(dst, want_g)) and bool(torch.allclose(tot, torch.full_like(tot, self.world * (self.world + 1) / 2.0)))
         except Exception:                                     # noqa: BLE001 -- any failure means "fall back"
             ok = False
         return agree(ok, self.device, self.group)

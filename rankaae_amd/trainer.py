@@ -138,7 +138,7 @@ class Trainer:
         return out
 
     def train(self, callback=None):
-        from .parallel import average_, broadcast_from_rank0, broadcast_tensor_from_rank0, epoch_schedule
+        from .parallel import broadcast_from_rank0, broadcast_tensor_from_rank0, epoch_schedule
         eng = self.engine
         lead = self.rank == 0
         best_combined_metric = 10.0
@@ -175,9 +175,7 @@ class Trainer:
             if not smooth:
                 tl["smooth"] = 0.0
             if self.world > 1:
-                with torch.cuda.stream(eng.stream):
-                    average_(bn_buffers, self.pg)
-                eng.stream.synchronize()
+                eng.average_over_ranks(bn_buffers)
             z, vl = eng.validate(val_spec, val_aux)
             if epoch % 10 == 0 and lead:
                 self.loss_logger.info(
