@@ -87,6 +87,10 @@ CASES = {
     # implementation can be held to these values over two whole epochs (tests/test_engine_gpu.py::test_p4_*).
     "fc_frozen": (700, 256, dict(ae_form="FC", batch_size=64, max_epoch=2, lr_base=0.0), 5, 4321),
     "compact_frozen": (700, 256, dict(ae_form="compact", batch_size=64, max_epoch=2, lr_base=0.0), 5, 4321),
+    # BASELINE configs[0]: example/fix_config.yaml as it stands (FC, batch 1024, 7000 x 256), one epoch free and two
+    # epochs frozen (five steps per epoch, the last one the ragged 804-row batch).
+    "fc_example": (7000, 256, dict(ae_form="FC", batch_size=1024, max_epoch=1), 2, 2022),
+    "fc_example_frozen": (7000, 256, dict(ae_form="FC", batch_size=1024, max_epoch=2, lr_base=0.0), 2, 2022),
 }
 
 

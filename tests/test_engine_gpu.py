@@ -31,10 +31,15 @@ P2  teacher-forced, at PHASE granularity: the oracle's state (weights, BN statis
     phases), and the kernels here sum in another order: a tensor that misses 5e-3 (in any case) is judged against a
     FLOAT64 repeat of the same oracle step (same parameters, inputs and replayed random tensors,
     ``oracle_float64_gradients``): HIP's distance from it must be within 3x the reference-fp32 distance.
-    One more legitimate discontinuity, not covered by these cases: a PReLU input that is pure rounding residue
-    (measured with another seed at B=256: T1[200, 2, 126] = +2.98e-8 here, <= 0 in the reference) picks the other
-    slope, which moves one sample's gradient at one position by ~30 % and every weight gradient upstream of it by
-    ~1/B; everything else of that step agreed with float64 to 1e-9 (RAAE_P2_REPORT / RAAE_P2_DUMP show this).
+    One more legitimate discontinuity: a PReLU input that is rounding noise around zero picks the other slope in
+    one of two fp32 implementations; that moves one sample's gradient at one unit by the slope ratio and every weight
+    gradient upstream of it by ~1/sqrt(B) of its size.  At BASELINE configs[0]'s batch (``fc_example``: 1024 rows x 64
+    units x 8 layers, pre-activations 1e-6 ... 4e-5 of their scale apart between the two forwards) a phase holds a
+    handful of such entries.  They are not excused but ACCOUNTED for (``kink_adjusted``): the entries where HIP's
+    stored pre-activation and the oracle's lie on different sides of zero, both within 1e-4 of the layer's scale, are
+    listed, the float64 repeat is made once more with exactly those branches taken HIP's way, and HIP's distance
+    from THAT gradient must meet the same 3x-the-reference's-own-distance bound (measured on fc_example step 1,
+    reconstruction phase, five entries: 5.6e-5 before, 1.1e-5 after, reference fp32 1.2e-5).
     The Adam update itself is pinned to torch.optim in tests/test_ops_gpu.py.
 Free-running K-step equality is NOT tested: the trajectory is chaotic (SURVEY finding 8).
 The engine runs in ``rng_mode="host"``: its tape is drawn from the global torch CPU
@@ -114,7 +119,8 @@ def rel_close(a, b, tol, what):
     assert abs(a - b) <= tol * abs(b) + 1e-7, f"{what}: hip {a!r} vs ref {b!r} (rel {abs(a - b) / (abs(b) + 1e-30):.2e})"
 
 
-@pytest.mark.parametrize("case", ["fc_small", "fc_c2", "fc_adam_nodrop", "fc_512_aux12", "compact_small", "compact_c2"])
+@pytest.mark.parametrize("case", ["fc_small", "fc_c2", "fc_adam_nodrop", "fc_512_aux12", "compact_small", "compact_c2",
+                                  "fc_example"])
 def test_p1_first_step_matches_reference_golden(case):
     g, cfg, spec, aux = load_case(case)
     torch.set_num_threads(1)
@@ -194,10 +200,20 @@ class RandomTape:
         torch.randn, torch.randn_like, self.F.dropout = self._randn, self._randn_like, self._dropout
 
 
-def oracle_float64_gradients(spec, aux, cfg, pre_state, post_states, tape, rows, alpha0, members):
+def prelu_modules(tr):
+    """The PReLU modules of the oracle's three networks in a fixed order (the kink bookkeeping below counts their
+    forward calls in execution order, which is the same in every repeat of a step)."""
+    return [m for net in (tr.encoder, tr.decoder, tr.discriminator) for m in net.modules()
+            if isinstance(m, torch.nn.PReLU)]
+
+
+def oracle_float64_gradients(spec, aux, cfg, pre_state, post_states, tape, rows, alpha0, members, branches=None):
     """The oracle's step repeated in float64 from the same parameters, inputs and (replayed) random tensors,
     with the fp32 run's post-phase parameters forced after every phase: per phase, the exact-arithmetic
-    gradients in the parameter order of the test."""
+    gradients in the parameter order of the test.  ``branches = {call: [(index, positive), ...]}``: the ``call``-th
+    PReLU forward of the step sees the listed input entries on the stated side of zero (where its own value lies on
+    the other side a constant of twice its size is subtracted; values and gradients elsewhere are untouched) -- the
+    exact gradient of the step with those branches taken."""
     state = torch.get_rng_state()
     tr = ref_train.OracleTrainer(spec, aux, cfg)
     torch.set_rng_state(state)
@@ -205,6 +221,21 @@ def oracle_float64_gradients(spec, aux, cfg, pre_state, post_states, tape, rows,
     for key, m in mods.items():
         m.load_state_dict(pre_state[key])
         m.double().train()
+    if branches:
+        calls = [0]
+
+        def take_branches(mod, inp):
+            calls[0] += 1
+            todo = branches.get(calls[0] - 1)
+            if todo:
+                z = inp[0]
+                delta = torch.zeros_like(z)
+                for index, positive in todo:
+                    if bool(z[index] > 0) != positive:
+                        delta[index] = -2.0 * z.detach()[index]
+                return (z + delta,)
+        for m in prelu_modules(tr):
+            m.register_forward_pre_hook(take_branches)
     grads = {}
     tr.phase_hook = lambda name: grads.__setitem__(name, [
         None if p.grad is None else p.grad.detach().clone() for grp in members[name] for p in mods[grp].parameters()])
@@ -225,7 +256,7 @@ def oracle_float64_gradients(spec, aux, cfg, pre_state, post_states, tape, rows,
 
 @pytest.mark.parametrize("case,steps", [("fc_small", (1, 2, 5, 8)), ("fc_adam_nodrop", (1, 3)), ("fc_512_aux12", (2,)),
                                         ("compact_small", (1, 2, 5, 8)), ("compact_nstyle5", (1, 3)),
-                                        ("compact_b4096", (1,)), ("fc_b4096", (1,))])
+                                        ("compact_b4096", (1,)), ("fc_b4096", (1,)), ("fc_example", (1, 5))])
 def test_p2_teacher_forced_steps(case, steps):
     _p2(case, steps, use_graph=False)
 
@@ -267,15 +298,34 @@ def _p2(case, steps, use_graph):
     names_e = {id(p): pre + n for mod, pre in ((eng.dis_mod, "D."), (eng.enc_mod, "E."), (eng.dec_mod, "G."))
                for n, p in mod.named_parameters()}
     o_grads, o_post, hip_grads = {}, {}, {}
-    tr.phase_hook = lambda name: o_grads.__setitem__(
-        name, [None if p.grad is None else p.grad.detach().clone() for p in o_params[name]])
+    def oracle_phase(name):
+        o_grads[name] = [None if p.grad is None else p.grad.detach().clone() for p in o_params[name]]
+        kink["phase_end"][name] = kink["calls"]
+    tr.phase_hook = oracle_phase
     tr.post_hook = lambda name: o_post.__setitem__(name, _snapshot(tr, name))
     o_styles, hip_styles = [], {}
     tr.encoder.register_forward_hook(lambda m, i, o: o_styles.append(o.detach().clone()))
+    # PReLU inputs of the oracle's dense networks, per forward call of the step (ordinal, network, layer, input):
+    # where HIP's stored pre-activation lies on the other side of zero by rounding noise, the two implementations took
+    # different slopes -- the kink arbiter of the gradient check below accounts for exactly those entries.
+    kink = {"calls": 0, "seen": [], "phase_end": {}}
+    where = {id(m): (key, i) for key, net in (("enc", tr.encoder), ("dec", tr.decoder))
+             for i, m in enumerate(mm for mm in net.modules() if isinstance(mm, torch.nn.PReLU))}
+
+    def note_kinks(mod, inp):
+        if id(mod) in where and inp[0].dim() == 2:
+            kink["seen"].append((kink["calls"],) + where[id(mod)] + (inp[0].detach().clone(),))
+        kink["calls"] += 1
+    for m in prelu_modules(tr):
+        m.register_forward_pre_hook(note_kinks)
+
+    hip_z = {}       # per phase: the pre-activations the dense networks hold when the phase's gradient is complete
 
     def pre(name, P):
         hip_grads[name] = eng.phase_gradient(P, name).cpu()
         hip_styles[name] = P.enc.out.detach().cpu().clone()
+        if hasattr(P.enc, "z"):
+            hip_z[name] = {"enc": [z.float().cpu() for z in P.enc.z], "dec": [z.float().cpu() for z in P.dec.z]}
     eng.phase_hook = pre
 
     def force(name, P):      # engine <- oracle state right after the oracle's optimizer step of this phase
@@ -315,6 +365,7 @@ def _p2(case, steps, use_graph):
                 load_engine_from_oracle()       # ... then put the oracle's pre-step state back
                 hip_grads.clear()
         o_styles.clear()
+        kink.update(calls=0, seen=[], phase_end={})
         aux_b = torch.tensor(tr.train_aux[rows], dtype=torch.float32)
         arbiter = k in steps       # see the gradient check below
         if arbiter:
@@ -351,6 +402,35 @@ def _p2(case, steps, use_graph):
                         continue
                 bad.append(f"step {k} loss {key}: hip {got[key]!r} ref {want[key]!r}")
         g64 = None              # float64 repeat of this step, made on demand
+        g64_kink = {}
+
+        def kink_adjusted(name):
+            """float64 gradients of phase ``name`` with every PReLU branch HIP took differently from the oracle
+            because the input is rounding noise around zero (|z| <= 1e-4 of the layer's largest input on both sides;
+            the two fp32 forwards are measured 1e-6 ... 4e-5 of that scale apart, growing with depth behind the
+            BatchNorms).  Per network the LAST forward of the phase is the one its gradients come from and the one
+            the engine's workspace still holds.  Returns (gradients or None, [(network, layer, row, unit, z oracle,
+            z hip)])."""
+            ends = sorted(kink["phase_end"].values())
+            first = ([0] + ends)[ends.index(kink["phase_end"][name])]
+            last = {}
+            for call, net, layer, z in kink["seen"]:
+                if first <= call < kink["phase_end"][name]:
+                    last[(net, layer)] = (call, z)
+            branches, took = {}, []
+            for (net, layer), (call, z) in last.items():
+                h = hip_z.get(name, {}).get(net)
+                if h is None or h[layer].shape != z.shape:
+                    continue
+                top = float(z.abs().max())
+                for r, u in ((h[layer] > 0) != (z > 0)).nonzero().tolist():
+                    if abs(float(z[r, u])) <= 1e-4 * top and abs(float(h[layer][r, u])) <= 1e-4 * top:
+                        branches.setdefault(call, []).append(((r, u), bool(h[layer][r, u] > 0)))
+                        took.append((net, layer, r, u, float(z[r, u]), float(h[layer][r, u])))
+            if not took:
+                return None, took
+            return oracle_float64_gradients(spec, aux, cfg, pre_state, dict(o_post), tape, rows, alpha0, members,
+                                            branches=branches)[name], took
         for name in members:
             if name == "smoothness" and not smooth:
                 continue
@@ -386,6 +466,20 @@ def _p2(case, steps, use_graph):
                         print("f64", g64[name][ip].flatten()[:256])
                     if e_hip <= 3.0 * e_ref + 1e-5 * phase_max + 1e-7:
                         continue
+                    # Last arbiter, for PReLU branches fp32 cannot decide: the float64 gradients of the same step
+                    # with the branches HIP took at inputs that are rounding noise around zero (kink_adjusted).
+                    if name not in g64_kink:
+                        g64_kink[name] = kink_adjusted(name)
+                    adj, took = g64_kink[name]
+                    if adj is not None and adj[ip] is not None:
+                        e_hip = float((mine_g - adj[ip]).abs().max())
+                        report.append((e_hip / (scale + 1e-30), f"  ^ vs float64 with HIP's PReLU branches at "
+                                                                f"{len(took)} near-zero inputs: hip {e_hip:.2e}"))
+                        if e_hip <= 3.0 * e_ref + 1e-5 * phase_max + 1e-7:
+                            print(f"\n{case} step {k} {name} {names_e[id(p_e)]}: hip vs float64 {e_hip:.2e} (reference "
+                                  f"fp32 {e_ref:.2e}) once float64 takes HIP's side at the near-zero PReLU inputs "
+                                  f"(net, layer, row, unit, z oracle, z hip) {took}")
+                            continue
                 if err > tol * scale + 1e-5 * phase_max + 1e-7:
                     bad.append(f"step {k} {name} grad {names_e[id(p_e)]}: err {err:.3e} vs |g|inf {scale:.3e}")
         if os.environ.get("RAAE_P2_REPORT"):       # debugging aid: the largest relative gradient errors
@@ -463,7 +557,7 @@ def test_paired_forwards_change_nothing(case, extra):
     assert len(out[0][1]) == len(out[1][1]) and all(torch.equal(x, y) for x, y in zip(out[0][1], out[1][1]))
 
 
-@pytest.mark.parametrize("case", ["fc_frozen", "compact_frozen"])
+@pytest.mark.parametrize("case", ["fc_frozen", "compact_frozen", "fc_example_frozen"])
 def test_p4_frozen_weights_free_running_matches_reference_golden(case, tmp_path):
     """P4 (module docstring): the product entry point -- ``Trainer.from_data(...).train()`` with hipGraph replay,
     ``rng_mode: host`` -- runs two whole epochs FREE (no teacher forcing) and every number the REAL reference
