@@ -722,6 +722,21 @@ extern "C" int raae_grad_materialize(const raae_grad_t* go, int B, int C, int L,
     RAAE_LAUNCH_RET();
 }
 
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? (int)strtol(e, nullptr, 0) : dflt; }
+// Which block shapes run their large-batch (`BIG`) instance from RAAE_BIG_ROWS rows on: bit k = block shape k of
+// raae_block_shapes.inc, bit 7 = the generic instance.  Measured per kernel alone at 4096 rows (bench.py
+// --roofline-detail, us, BIG / plain): the 16-byte paths pay for the 64- and 256-point rows of shapes 0, 5, 6 and
+// cost the short rows their occupancy (190 against 80 registers) -- phase B backward of decoder block 1 75 / 31,
+// of decoder block 0 35 / 17, of encoder block 1 29 / 17, of encoder block 0 63 / 46; phase A backward of decoder
+// block 1 34 / 39-51; weight gradients of encoder block 1 59 / 45, of encoder block 0 54 / 63.
+// Environment overrides for tuning: RAAE_BIG_MASK_{FWD_A,FWD_B,BWD_B,BWD_A,WGRAD}.
+enum { kFamFwdA, kFamFwdB, kFamBwdB, kFamBwdA, kFamWgrad };
+static const int kBigMask[5] = {env_int("RAAE_BIG_MASK_FWD_A", 0xe1), env_int("RAAE_BIG_MASK_FWD_B", 0xe1),
+                                env_int("RAAE_BIG_MASK_BWD_B", 0xe0), env_int("RAAE_BIG_MASK_BWD_A", 0xf1),
+                                env_int("RAAE_BIG_MASK_WGRAD", 0xf1)};
+static bool use_big(int B, int kind, int family) {
+    return B >= RAAE_BIG_ROWS && ((kBigMask[family] >> (kind < 0 ? 7 : kind)) & 1);
+}
 // ---- shape-specialised instances of the fused block kernels (raae_block_shapes.inc)
 // (`big`: the instance for batches of >= 1024 rows, which carries the 16-byte staging / elementwise paths)
 #define RAAE_LAUNCH_KIND_BIG(KERNEL, ...) if (big) switch (kind) { \
@@ -789,7 +804,7 @@ extern "C" int raae_block_fwd_a(const raae_block_fwd_a_t* in, int* nparts, void*
     const int rc = prep_block_fwd_a(in, a, grid, lds, kind);
     if (rc) return rc;
     if (nparts) *nparts = grid;
-    const bool big = a.B >= RAAE_BIG_ROWS;
+    const bool big = use_big(a.B, kind, kFamFwdA);
     RAAE_LAUNCH_KIND_BIG(block_fwd_a_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a)
     RAAE_LAUNCH_RET();
 }
@@ -821,7 +836,7 @@ extern "C" int raae_block_fwd_b(const raae_block_fwd_b_t* in, int* nparts, void*
     const int rc = prep_block_fwd_b(in, a, grid, lds, kind);
     if (rc) return rc;
     if (nparts) *nparts = grid;
-    const bool big = a.B >= RAAE_BIG_ROWS;
+    const bool big = use_big(a.B, kind, kFamFwdB);
     RAAE_LAUNCH_KIND_BIG(block_fwd_b_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a)
     RAAE_LAUNCH_RET();
 }
@@ -879,9 +894,9 @@ extern "C" int raae_block_fwd_a2(const raae_block_fwd_a_t* x, const raae_block_f
     const size_t lds = l1 > l2 ? l1 : l2;
     const dim3 grid(g1 + g2);
     RAAE_FWD_PAIRS(block_fwd_a2_kernel)
-    { const int kind = k1; const raae_block_fwd_a_t& a = k.x; const bool big = a.B >= RAAE_BIG_ROWS;
+    { const int kind = k1; const raae_block_fwd_a_t& a = k.x; const bool big = use_big(a.B, kind, kFamFwdA);
       RAAE_LAUNCH_KIND_BIG(block_fwd_a_kernel, dim3(g1), dim3(256), l1, (hipStream_t)stream, a) }
-    { const int kind = k2; const raae_block_fwd_a_t& a = k.y; const bool big = a.B >= RAAE_BIG_ROWS;
+    { const int kind = k2; const raae_block_fwd_a_t& a = k.y; const bool big = use_big(a.B, kind, kFamFwdA);
       RAAE_LAUNCH_KIND_BIG(block_fwd_a_kernel, dim3(g2), dim3(256), l2, (hipStream_t)stream, a) }
     RAAE_LAUNCH_RET();
 }
@@ -901,9 +916,9 @@ extern "C" int raae_block_fwd_b2(const raae_block_fwd_b_t* x, const raae_block_f
     const size_t lds = l1 > l2 ? l1 : l2;
     const dim3 grid(g1 + g2);
     RAAE_FWD_PAIRS(block_fwd_b2_kernel)
-    { const int kind = k1; const raae_block_fwd_b_t& a = k.x; const bool big = a.B >= RAAE_BIG_ROWS;
+    { const int kind = k1; const raae_block_fwd_b_t& a = k.x; const bool big = use_big(a.B, kind, kFamFwdB);
       RAAE_LAUNCH_KIND_BIG(block_fwd_b_kernel, dim3(g1), dim3(256), l1, (hipStream_t)stream, a) }
-    { const int kind = k2; const raae_block_fwd_b_t& a = k.y; const bool big = a.B >= RAAE_BIG_ROWS;
+    { const int kind = k2; const raae_block_fwd_b_t& a = k.y; const bool big = use_big(a.B, kind, kFamFwdB);
       RAAE_LAUNCH_KIND_BIG(block_fwd_b_kernel, dim3(g2), dim3(256), l2, (hipStream_t)stream, a) }
     RAAE_LAUNCH_RET();
 }
@@ -942,7 +957,7 @@ extern "C" int raae_block_bwd_b(const raae_block_bwd_b_t* in, int* nparts, void*
     const int rc = prep_block_bwd_b(in, a, grid, lds, kind);
     if (rc) return rc;
     if (nparts) *nparts = grid;
-    const bool big = a.B >= RAAE_BIG_ROWS;
+    const bool big = use_big(a.B, kind, kFamBwdB);
     RAAE_LAUNCH_KIND_BIG(block_bwd_b_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a)
     RAAE_LAUNCH_RET();
 }
@@ -972,7 +987,7 @@ extern "C" int raae_block_bwd_a(const raae_block_bwd_a_t* in, int* nparts, void*
     const int grid = a.ngroups < 512 ? a.ngroups : 512;
     if (nparts) *nparts = grid;
     const size_t lds = sizeof(float) * ((size_t)a.S * per + wfl);
-    const bool big = a.B >= RAAE_BIG_ROWS;
+    const bool big = use_big(a.B, kind, kFamBwdA);
     RAAE_LAUNCH_KIND_BIG(block_bwd_a_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a)
     RAAE_LAUNCH_RET();
 }
@@ -980,7 +995,6 @@ extern "C" int raae_block_bwd_a(const raae_block_bwd_a_t* in, int* nparts, void*
 // workgroups per weight-gradient task (= slabs it writes); 64 -> 128: +2 % at B=256, +18 % at B=4096
 static const int kWgradTaskGridDefault = 128;
 // tuning knobs (environment, read once): RAAE_WGRAD_GRID workgroups per task, RAAE_WGRAD_S samples per group (0: automatic)
-static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 static const int kWgradTaskGrid = env_int("RAAE_WGRAD_GRID", kWgradTaskGridDefault);
 static const int kWgradForceS = env_int("RAAE_WGRAD_S", 0);
 // checks + task table + launch geometry of a block's weight-gradient tasks; `m` is filled
@@ -1058,7 +1072,7 @@ extern "C" int raae_block_wgrad(const raae_block_wgrad_t* in, int* nslab, void* 
     size_t dyn;
     const int rc = prep_block_wgrad(in, nslab, m, total, dyn, kind);
     if (rc) return rc;
-    const bool big = in->B >= RAAE_BIG_ROWS;
+    const bool big = use_big(in->B, kind, kFamWgrad);
     RAAE_LAUNCH_KIND_BIG(wgrad_multi_kernel, dim3(total), dim3(256), dyn, (hipStream_t)stream, m)
     RAAE_LAUNCH_RET();
 }
