@@ -282,6 +282,17 @@ int raae_conv_bwd_data(const raae_grad_t* go, int B, const raae_conv_t* cv, cons
 int raae_conv_bwd_weight(const raae_grad_t* go, int B, const raae_conv_t* cv, const raae_view_t* in,
                          float* dw, float* dbias, float* dslope, long slab_stride, int* nslab, void* stream);
 
+/* The decoder's head backward (reference sc/clustering/model.py:461, BatchNorm1d(C, affine=False) -> Conv1d(C, 1, 1)
+ * -> Softplus / ReLU, and its autograd) in ONE streaming pass instead of raae_conv_bwd_data + raae_conv_bwd_weight:
+ * din [B][C][L] = dL/d(BatchNorm output), din_partials {sum din, sum din*y} per workgroup (*din_nparts rows), and the
+ * parameter-gradient slabs dw [C], dbias [1] (*nslab of them).  raae_head_bwd_supported() != 0 says whether the shape
+ * is one this kernel takes (K = 1, Cout = 1, Cin 4 or 8, rows of whole quads, a plain BatchNorm view, `go` without a
+ * BatchNorm of its own); raae_conv_fwd runs the matching forward kernel for the same shapes by itself. */
+int raae_head_bwd_supported(const raae_grad_t* go, int B, const raae_conv_t* cv, const raae_view_t* in);
+int raae_head_bwd(const raae_grad_t* go, int B, const raae_conv_t* cv, const float* w, const raae_view_t* in,
+                  float* din, double* din_partials, int* din_nparts, float* dw, float* dbias, long slab_stride,
+                  int* nslab, void* stream);
+
 /* nn.Linear applied along the LENGTH axis of [B][C][Lin] -> [B][C][E] (excitation fc1 / fc2, reference
  * model.py:44-47,89-93,125-128,164-167); out_slope / statistics are per CHANNEL c (PReLU on dim 1). */
 int raae_lenlin_fwd(const raae_view_t* in, int B, int C, int Lin, const float* w, const float* bias, int E, float* out,
@@ -423,7 +434,7 @@ int raae_event_destroy(void* ev);
 int raae_stream_sync(void* stream);
 const char* raae_error_string(int code);
 int raae_device_info(int* cu_count, int* lds_bytes, char* name, int name_len);
-#define RAAE_ABI_VERSION 10
+#define RAAE_ABI_VERSION 11
 int raae_abi_version(void);
 /* First 16 hex digits of sha256 over include/rankaae_hip.h + csrc/raae_*.{h,inc,hip} at build time
  * (build.sh); the Python loader recomputes it and refuses a library built from other sources. */

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librankaae_hip.so")
 
 RAAE_MAX_PARTS = 512
-ABI_VERSION = 10
+ABI_VERSION = 11
 IN_NONE, IN_PRELU_BN_DROP, IN_PRELU_DROP = 0, 1, 2
 OUT_RAW, OUT_STATS_PRELU, OUT_STATS_RAW, OUT_SOFTPLUS, OUT_RELU = 0, 1, 2, 3, 4
 G_DIRECT, G_SOFTPLUS, G_PRELU_BN, G_PRELU, G_RELU = 0, 1, 2, 3, 4
@@ -163,6 +163,8 @@ SIGNATURES = {
     "raae_conv_fwd": (_I, [_PV, _I, _PC, _P, _P, _P, _I, _P, _P, _PI, _I, _P]),
     "raae_conv_bwd_data": (_I, [_PG, _I, _PC, _P, _PV, _P, _I, _P, _PI, _P]),
     "raae_conv_bwd_weight": (_I, [_PG, _I, _PC, _PV, _P, _P, _P, _L, _PI, _P]),
+    "raae_head_bwd_supported": (_I, [_PG, _I, _PC, _PV]),
+    "raae_head_bwd": (_I, [_PG, _I, _PC, _P, _PV, _P, _P, _PI, _P, _P, _L, _PI, _P]),
     "raae_lenlin_fwd": (_I, [_PV, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P, _PI, _P]),
     "raae_lenlin_bwd_data": (_I, [_PG, _I, _I, _I, _P, _PV, _I, _P, _I, _P, _PI, _P]),
     "raae_lenlin_bwd_weight": (_I, [_PG, _I, _I, _I, _PV, _I, _P, _P, _P, _L, _PI, _P]),

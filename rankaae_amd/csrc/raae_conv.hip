@@ -471,6 +471,7 @@ __host__ __device__ constexpr int clg2(int v) { int s = -1; if (v > 0 && !(v & (
 #include "raae_conv_tiled.inc"
 #include "raae_block_fused.inc"
 #include "raae_conv_strip.inc"
+#include "raae_head.inc"
 
 int slices_for(long per_channel, int C) {
     long n = (per_channel + 255) / 256;
@@ -535,6 +536,16 @@ extern "C" int raae_conv_fwd(const raae_view_t* in, int B, const raae_conv_t* cv
     ConvFwdArgs a;
     a.in = *in; a.B = B; a.cv = *cv; a.w = w; a.bias = bias; a.out = out; a.stats_kind = stats_kind;
     a.out_slope = out_slope; a.out_partials = out_partials; a.act = act;
+    if (stats_kind == RAAE_OUT_RAW && head_shape_ok(cv, in) && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+        // the decoder's head: BatchNorm -> Conv1d(C, 1, 1) -> activation as one streaming pass (raae_head.inc)
+        HeadFwdArgs h;
+        h.in = *in; h.B = B; h.L = cv->Lin; h.w = w; h.bias = bias; h.out = out; h.act = act; h.nq = B * (cv->Lin >> 2);
+        const int grid = head_grid(h.nq, cv->Cin <= 4 ? kHeadU : kHeadU / 2);
+        if (out_nparts) *out_nparts = 0;
+        if (cv->Cin == 4) hipLaunchKernelGGL(head_fwd_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, h);
+        else hipLaunchKernelGGL(head_fwd_kernel<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, h);
+        RAAE_LAUNCH_RET();
+    }
     if (conv_fwd_strip(a, out_nparts, (hipStream_t)stream)) RAAE_LAUNCH_RET();
     const long per_in = (long)cv->Cin * (cv->Lin + 2 * (cv->transposed ? 0 : cv->pad));
     if (conv_nw(cv) <= 1024 && (stats_kind == RAAE_OUT_RAW || cv->Cout <= CT_MAXCH) && per_in <= kTileBudget) {
@@ -554,6 +565,28 @@ extern "C" int raae_conv_fwd(const raae_view_t* in, int B, const raae_conv_t* cv
     a.nsl = slices_for((long)B * cv->Lout, cv->Cout);
     if (out_nparts) *out_nparts = a.nsl;
     hipLaunchKernelGGL(conv_fwd_kernel, dim3(a.nsl * cv->Cout), dim3(256), 0, (hipStream_t)stream, a);
+    RAAE_LAUNCH_RET();
+}
+
+extern "C" int raae_head_bwd_supported(const raae_grad_t* go, int B, const raae_conv_t* cv, const raae_view_t* in) {
+    return go && cv && in && B > 0 && conv_ok(cv) && head_shape_ok(cv, in) && !go->has_bn && !go->slope && go->g &&
+           (go->act == RAAE_OUT_RAW || go->raw) && (reinterpret_cast<uintptr_t>(go->g) & 15) == 0 &&
+           (reinterpret_cast<uintptr_t>(go->raw) & 15) == 0;
+}
+
+extern "C" int raae_head_bwd(const raae_grad_t* go, int B, const raae_conv_t* cv, const float* w, const raae_view_t* in,
+                             float* din, double* din_partials, int* din_nparts, float* dw, float* dbias,
+                             long slab_stride, int* nslab, void* stream) {
+    RAAE_CHECK_ARG(raae_head_bwd_supported(go, B, cv, in) && w && din && din_partials && dw && dbias && slab_stride > 0 &&
+                   (reinterpret_cast<uintptr_t>(din) & 15) == 0);
+    HeadBwdArgs h;
+    h.go = *go; h.in = *in; h.B = B; h.L = cv->Lin; h.w = w; h.din = din; h.din_partials = din_partials; h.dw = dw;
+    h.dbias = dbias; h.slab_stride = slab_stride; h.nq = B * (cv->Lin >> 2);
+    const int grid = head_grid(h.nq, 2);
+    if (din_nparts) *din_nparts = grid;
+    if (nslab) *nslab = grid;
+    if (cv->Cin == 4) hipLaunchKernelGGL(head_bwd_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, h);
+    else hipLaunchKernelGGL(head_bwd_kernel<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, h);
     RAAE_LAUNCH_RET();
 }
 

@@ -286,14 +286,20 @@ class CompactNet:
         else:
             go = ops.make_grad(g_out.view(b, 1, self.out_dim), raw=ws.spec.view(b, 1, self.out_dim), act=self.act)
             vf = ops.make_view(wl.Y, None, self._bn(self.bn_f, wl.pY, wl.nY, b * last.Lout, True, False))
-            if pending is None and not eng._branch and self.fused and last.Cin <= 8 and last.Cout <= 8:
-                # serial chain: the head's weight gradient rides in the last block's backward phase B
-                head = [(go, self.cvf, vf, self.conv_f)]
-                pending = (ops.block_wgrad_args(b, [(go, self.cvf, vf, G(self.conv_f.weight), G(self.conv_f.bias))], [],
-                                                eng.arena.n), head, [])
+            if bool(eng.cfg.get("fused_head", True)) and ops.head_bwd_supported(go, b, self.cvf, vf):
+                # one streaming pass: data gradient, its BatchNorm-backward sums and the head's parameter gradients
+                ws.ndBnF, ns = ops.head_bwd(go, b, self.cvf, self.conv_f.weight, vf, ws.dBnF, ws.pdBnF,
+                                            G(self.conv_f.weight), G(self.conv_f.bias), eng.arena.n)
+                eng.note_slabs([self.conv_f.weight, self.conv_f.bias], ns)
             else:
-                self._cw(go, b, self.cvf, vf, self.conv_f, None)
-            ws.ndBnF = ops.conv_bwd_data(go, b, self.cvf, self.conv_f.weight, vf, ws.dBnF, False, ws.pdBnF)
+                if pending is None and not eng._branch and self.fused and last.Cin <= 8 and last.Cout <= 8:
+                    # serial chain: the head's weight gradient rides in the last block's backward phase B
+                    head = [(go, self.cvf, vf, self.conv_f)]
+                    pending = (ops.block_wgrad_args(b, [(go, self.cvf, vf, G(self.conv_f.weight), G(self.conv_f.bias))],
+                                                    [], eng.arena.n), head, [])
+                else:
+                    self._cw(go, b, self.cvf, vf, self.conv_f, None)
+                ws.ndBnF = ops.conv_bwd_data(go, b, self.cvf, self.conv_f.weight, vf, ws.dBnF, False, ws.pdBnF)
             gy = dict(g=ws.dBnF, bn=self.bn_f, parts=ws.pdBnF, nparts=ws.ndBnF)
 
         # Serial chain (batches below eng.overlap_min_batch): a block's weight-gradient tasks wait as `pending` and

@@ -457,6 +457,22 @@ def conv_bwd_data(go, B, cv, w, view, din, accumulate, din_partials=None):
                                                            extra_out=1 if go.raw else 0), launch)
 
 
+def head_bwd_supported(go, B, cv, view):
+    return bool(_lib.load().raae_head_bwd_supported(C.byref(go), B, C.byref(cv), C.byref(view)))
+
+
+def head_bwd(go, B, cv, w, view, din, din_partials, dw, dbias, slab_stride):
+    """The decoder head's backward in one pass (``raae_head_bwd``): returns (partial rows of din, slabs of dw/dbias)."""
+    def launch():
+        n, ns = C.c_int(0), C.c_int(0)
+        check(_lib.load().raae_head_bwd(C.byref(go), B, C.byref(cv), _ptr(w), C.byref(view), _ptr(din),
+                                        _ptr(din_partials, torch.float64), C.byref(n), _ptr(dw), _ptr(dbias), slab_stride,
+                                        C.byref(ns), _stream()), "raae_head_bwd")
+        return n.value, ns.value
+    # reads g, out and the C input rows, writes the C gradient rows
+    return _probed("head_bwd", 4 * B * cv.Lin * (2 * cv.Cin + 2) + 4 * (cv.Cin + 1), launch)
+
+
 def conv_bwd_weight(go, B, cv, view, dw, dbias, dslope, slab_stride):
     def launch():
         n = C.c_int(0)

@@ -497,6 +497,69 @@ def test_conv_family_fwd_bwd(kind, B, Cin, Lin, cfg):
     close(tot[:, 1], (want_din * r["v"].detach().double()).sum((0, 2)), 1e-4, atol, "din*y partial sum")
 
 
+@pytest.mark.parametrize("B,C,L,act", [(256, 4, 256, 3), (37, 4, 256, 3), (4099, 4, 256, 4), (130, 8, 64, 0)])
+def test_decoder_head_kernels(B, C, L, act):
+    """BatchNorm1d(C, affine=False) -> Conv1d(C, 1, 1) -> Softplus(beta=2) / ReLU / nothing (reference model.py:461)
+    through the streaming head kernels: forward inside ``raae_conv_fwd``, backward ``raae_head_bwd`` (data gradient,
+    its BatchNorm-backward sums and the parameter-gradient slabs in one pass) against torch autograd, and against the
+    per-layer kernels they replace (``raae_conv_bwd_data`` + ``raae_conv_bwd_weight``)."""
+    torch.manual_seed(B + C)
+    X = torch.randn(B, C, L) * 1.7 + 0.3
+    conv = torch.nn.Conv1d(C, 1, 1)
+    G = torch.randn(B, 1, L)
+    # the expectation in float64 (torch's fp32 weight gradient is itself ~1e-2 off on a sum of a million terms)
+    conv64 = torch.nn.Conv1d(C, 1, 1).double()
+    conv64.load_state_dict({k: v.double() for k, v in conv.state_dict().items()})
+    X64 = X.double()
+    mean, var = X64.mean((0, 2)), X64.var((0, 2), unbiased=False)
+    yhat = ((X64 - mean[None, :, None]) / torch.sqrt(var[None, :, None] + 1e-5)).detach().requires_grad_(True)
+    pre = conv64(yhat)
+    out = F.softplus(pre, beta=2) if act == 3 else (torch.relu(pre) if act == 4 else pre)
+    (out * G.double()).sum().backward()
+    conv.weight.grad, conv.bias.grad = conv64.weight.grad.float(), conv64.bias.grad.float()
+
+    Xd = dev(X)
+    pin = _partials_of(X).to(DEV)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    view = ops.make_view(Xd, None, ops.make_bn(pin, 2, B * L, rm, rv, update_running=True))
+    cv = ops.make_conv(C, L, 1, L, 1, 1, 0, False, 1, False)
+    w, bias = dev(conv.weight.detach()), dev(conv.bias.detach())
+    got = torch.empty(B, 1, L, device=DEV)
+    ops.conv_fwd(view, B, cv, w, bias, got, _lib.OUT_RAW, None, None, act)
+    close(got, out.detach(), 2e-5, 2e-5, "head forward")
+    close(rm, 0.1 * mean.float(), 1e-4, 1e-6, "running mean")
+
+    view = ops.make_view(Xd, None, ops.make_bn(pin, 2, B * L))
+    go = ops.make_grad(dev(G), raw=got, act=act)
+    assert ops.head_bwd_supported(go, B, cv, view)
+    stride = 128
+    slabs = torch.zeros(_lib.RAAE_MAX_PARTS, stride, device=DEV)
+    din = torch.empty(B, C, L, device=DEV)
+    pdin = torch.zeros(_lib.RAAE_MAX_PARTS, C, 2, dtype=torch.float64, device=DEV)
+    nd, ns = ops.head_bwd(go, B, cv, w, view, din, pdin, slabs[0, 0:], slabs[0, 64:], stride)
+    assert 1 <= nd <= 256 and ns == nd
+    tot = slabs[:ns].sum(0)
+    scale = float(G.abs().mean()) * (B * L) ** 0.5
+    close(tot[:C].view(1, C, 1), conv.weight.grad, 1e-4, 2e-6 * scale, "dw")
+    close(tot[64:65], conv.bias.grad, 1e-4, 2e-6 * scale, "dbias")
+    close(din, yhat.grad, 1e-5, 1e-6, "din")
+    want = yhat.grad.double()
+    atol = max(1e-3, 5e-5 * (B * L) ** 0.5)
+    ptot = pdin[:nd].sum(0).cpu()
+    close(ptot[:, 0], want.sum((0, 2)), 1e-4, atol, "din partial sum")
+    close(ptot[:, 1], (want * yhat.detach().double()).sum((0, 2)), 1e-4, atol, "din*y partial sum")
+
+    # the per-layer kernels on the same inputs
+    slabs2 = torch.zeros(_lib.RAAE_MAX_PARTS, stride, device=DEV)
+    din2 = torch.empty(B, C, L, device=DEV)
+    pdin2 = torch.zeros(_lib.RAAE_MAX_PARTS, C, 2, dtype=torch.float64, device=DEV)
+    ns2 = ops.conv_bwd_weight(go, B, cv, view, slabs2[0, 0:], slabs2[0, 64:], None, stride)
+    nd2 = ops.conv_bwd_data(go, B, cv, w, view, din2, False, pdin2)
+    close(din, din2, 1e-6, 1e-7, "din vs per-layer kernel")
+    close(tot[:C], slabs2[:ns2].sum(0)[:C], 1e-4, 1e-5 * scale, "dw vs per-layer kernel")
+    close(ptot, pdin2[:nd2].sum(0).cpu(), 1e-5, atol, "partials vs per-layer kernel")
+
+
 @pytest.mark.parametrize("B,Cin,K,s,rep,act", [(1100, 4, 11, 1, True, 0), (2051, 1, 11, 2, True, 0),
                                                 (4100, 4, 5, 2, False, 3)])       # 3 = RAAE_OUT_SOFTPLUS
 def test_conv_fwd_large_batch_plain_view(B, Cin, K, s, rep, act):
