@@ -343,6 +343,9 @@ def _probed(family, nbytes, launch, tag=None):
             launch()
         g.end()
         e0, e1 = Event(), Event()
+        # ALONE means alone: drain every stream first -- replays of a weight-gradient launch on a side stream were still
+        # running beside the next main-stream kernel's replays (its "alone" time then doubled or not, depending on timing)
+        torch.cuda.synchronize()
         e0.record()
         g.launch()
         e1.record()
