@@ -318,6 +318,16 @@ class CompactNet:
                 note_wgrad(pend, ops.block_wgrad(b, None, None, eng.arena.n, args=pend[0]))
             return None
 
+        forked = []          # branched graph: blocks whose weight-gradient launches wait for the next fork
+
+        def fork_wgrad():
+            if forked:
+                eng.join_side_streams(keep=int(eng.cfg.get("wgrad_overlap_depth", 1)) - 1)
+                with eng.side_stream():
+                    for pend in forked:
+                        note_wgrad(pend, ops.block_wgrad(b, None, None, eng.arena.n, args=pend[0]))
+                forked.clear()
+
         for i in reversed(range(len(self.blocks))):
             k, w, m = self.blocks[i], ws.blk[i], self.blocks[i].m
             need_dx = i > 0 or dx_in is not None
@@ -373,12 +383,15 @@ class CompactNet:
                     [(g_, c_, e_, l_, v_, G_(mod.weight), G_(mod.bias)) for g_, c_, e_, l_, v_, mod in lins],
                     eng.arena.n)
                 if eng._branch:
-                    # `wgrad_overlap_depth` blocks' weight-gradient launches may be in flight at once (default 1: the
-                    # previous block's are joined before this one forks)
-                    eng.join_side_streams(keep=int(eng.cfg.get("wgrad_overlap_depth", 1)) - 1)
-                    with eng.side_stream():
-                        ns = ops.block_wgrad(b, None, None, eng.arena.n, args=wargs)
-                    note_wgrad((wargs, convs, lins), ns)
+                    # One fork of the captured graph carries the weight-gradient launches of `wgrad_fork_blocks`
+                    # consecutive blocks (default 2): an edge between two hardware queues costs the main chain ~13 us
+                    # (rocprofv3 timeline of the 4096-row step: every fork delayed the next backward kernel by that
+                    # much), a weight-gradient launch that starts one block later costs nothing.
+                    # `wgrad_overlap_depth` such batches may be in flight at once (default 1: the previous one is
+                    # joined before the next forks).
+                    forked.append((wargs, convs, lins))
+                    if len(forked) >= int(eng.cfg.get("wgrad_fork_blocks", 2)) or i == 0:
+                        fork_wgrad()
                 else:
                     pending = (wargs, convs, lins)
                 if i > 0:
@@ -430,6 +443,7 @@ class CompactNet:
                 gy = dict(g=w.dR, bn=m.bn1, parts=w.pdR, nparts=w.ndR)
                 if m.bn1 is None:
                     gy = dict(g=w.dR, bn=None, parts=None, nparts=0)
+        fork_wgrad()
         if keep_pending:
             return pending
         flush(pending)
