@@ -206,11 +206,15 @@ __global__ __launch_bounds__(256) void rank_finalize_kernel(const RankWork* part
     if (totals == nullptr) {
         const int k = tid & 15, sl = tid >> 4;          // 16 slices
         long long np = 0, nn = 0; double sp = 0.0, sn = 0.0;
-        if (k < KA)
+        if (k < KA) {
+            // eight records' loads in flight per trip (up to 2048 records: 128 dependent round trips per lane otherwise,
+            // 36 us at 4096 rows); the sums keep their order
+#pragma unroll 8
             for (int p = sl; p < nparts; p += 16) {
                 np += part[p].n_pos[k]; nn += part[p].n_neg[k];
                 sp += part[p].s_pos[k]; sn += part[p].s_neg[k];
             }
+        }
         r_s[0][tid] = sp; r_s[1][tid] = sn; r_n[0][tid] = np; r_n[1][tid] = nn;
     }
     __syncthreads();
@@ -263,11 +267,13 @@ __global__ __launch_bounds__(256) void rank_totals_kernel(const RankWork* part, 
     __shared__ long long r_n[2][256];
     const int tid = threadIdx.x, k = tid & 15, sl = tid >> 4;
     long long np = 0, nn = 0; double sp = 0.0, sn = 0.0;
-    if (k < KA)
+    if (k < KA) {
+#pragma unroll 8
         for (int p = sl; p < nparts; p += 16) {
             np += part[p].n_pos[k]; nn += part[p].n_neg[k];
             sp += part[p].s_pos[k]; sn += part[p].s_neg[k];
         }
+    }
     r_s[0][tid] = sp; r_s[1][tid] = sn; r_n[0][tid] = np; r_n[1][tid] = nn;
     __syncthreads();
     if (tid < 16) {
