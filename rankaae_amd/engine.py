@@ -529,6 +529,7 @@ class StepEngine:
         self.tape = None
         self._slab_notes = None
         self.train_spec = self.train_aux = self.perm = None
+        self._perm_pin, self._perm_turn = None, 0
         self.phase_hook = None
         self.post_phase_hook = None
         self._capture = None
@@ -654,7 +655,23 @@ class StepEngine:
     def set_epoch(self, perm, alpha, start=0, stride=None):
         """``start``/``stride``: this rank's rows of global batch i are perm[start + i*stride : +b]
         (single GPU: start 0, stride = b, i.e. consecutive batches)."""
-        self.perm.copy_(torch.as_tensor(perm, dtype=torch.int64))
+        perm = torch.as_tensor(perm, dtype=torch.int64)
+        if perm.is_cuda:
+            self.perm.copy_(perm)
+        else:
+            # Through one of two pinned staging buffers, non-blocking: a copy from pageable memory makes the host wait
+            # for every step already queued on the stream, i.e. drains the pipeline once per epoch (17 steps at batch
+            # 4096).  A buffer is reused two epochs later; its event says the copy out of it has finished.
+            if self._perm_pin is None or self._perm_pin[0][0].numel() != self.perm.numel():
+                self._perm_pin = [(torch.empty(self.perm.numel(), dtype=torch.int64).pin_memory(), torch.cuda.Event())
+                                  for _ in range(2)]
+                self._perm_turn = 0
+            buf, done = self._perm_pin[self._perm_turn]
+            self._perm_turn ^= 1
+            done.synchronize()
+            buf.copy_(perm)
+            self.perm.copy_(buf, non_blocking=True)
+            done.record(torch.cuda.current_stream())
         self.cursor_start, self.cursor_stride = int(start), stride
         self._cursor_primed = False
         self._host_cursor = int(start)       # host mirror of the device row cursor (bounds check)
