@@ -80,6 +80,10 @@ INLINE_CASES = {
                           over=dict(ae_form="compact", batch_size=4096)),
     "fc_b4096": dict(n_rows=6000, n_points=256, data_seed=4, model_seed=42,
                      over=dict(ae_form="FC", batch_size=4096)),
+    # 1024 rows, conv networks: the large-batch kernel instances on the SERIAL chain (branches start at 2048 rows;
+    # the merged backward-B + weight-gradient launches here, the per-family instance masks of raae_conv.hip)
+    "compact_b1024": dict(n_rows=1600, n_points=256, data_seed=6, model_seed=43,
+                          over=dict(ae_form="compact", batch_size=1024)),
 }
 
 
@@ -256,7 +260,8 @@ def oracle_float64_gradients(spec, aux, cfg, pre_state, post_states, tape, rows,
 
 @pytest.mark.parametrize("case,steps", [("fc_small", (1, 2, 5, 8)), ("fc_adam_nodrop", (1, 3)), ("fc_512_aux12", (2,)),
                                         ("compact_small", (1, 2, 5, 8)), ("compact_nstyle5", (1, 3)),
-                                        ("compact_b4096", (1,)), ("fc_b4096", (1,)), ("fc_example", (1, 5))])
+                                        ("compact_b4096", (1,)), ("fc_b4096", (1,)), ("fc_example", (1, 5)),
+                                        ("compact_b1024", (1,))])
 def test_p2_teacher_forced_steps(case, steps):
     _p2(case, steps, use_graph=False)
 
