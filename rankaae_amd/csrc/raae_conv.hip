@@ -507,12 +507,16 @@ int pick_S(long floats_per_sample, long outputs_per_sample, int B, long lds_budg
     // large batches: about two groups per workgroup of a 512-workgroup grid, up to 4x the samples per group
     // (fewer barriers, more loads in flight per staging pass; measured at B = 4096: 180 -> 201 steps/s, 8x: 192)
     long want = (B + 1023) / 1024;
-    // small samples (a few KB per sample): ONE group per workgroup of the 512-workgroup grid -- such kernels are a chain
+    // small samples (a few KB per sample): ONE group per workgroup -- such kernels are a chain
     // of barrier-separated stages of a few microseconds each, and a second group repeats the chain
     // (measured at B = 4096: 217 -> 223 steps/s with the threshold anywhere between 1400 and 4400 floats per sample)
     static const long small_floats = getenv("RAAE_PICK_SMALL") ? atol(getenv("RAAE_PICK_SMALL")) : 2200;
     static const long small_mult = getenv("RAAE_PICK_MULT") ? atol(getenv("RAAE_PICK_MULT")) : 8;
-    if (floats_per_sample <= small_floats) want = (B + 511) / 512;
+    // ... of a 256-workgroup grid (RAAE_PICK_DIV): half as many partial-statistic rows for every consumer's prologue and
+    // half as many prologues; measured 1024 / 2048 / 4096 / 8192 rows: 521 -> 547, 390 -> 405, 272.5 -> 279.6,
+    // 170.5 -> 168.9 steps/s against 512 workgroups
+    static const long small_div = getenv("RAAE_PICK_DIV") ? atol(getenv("RAAE_PICK_DIV")) : 256;
+    if (floats_per_sample <= small_floats) want = (B + small_div - 1) / small_div;
     if (want > small_mult * S && floats_per_sample <= small_floats) want = small_mult * S;
     else
     if (want > 4 * S) want = 4 * S;
