@@ -179,7 +179,7 @@ def configs2_line(args, cfg0, dev):
             eng.set_epoch(torch.randperm(n_train, generator=gen), 0.7172)
         eng.step(b, smooth=True)
         i += 1
-    for _ in range(4):
+    for _ in range(20):          # eager emission, capture, first replays -- and the clocks of a GPU that sat idle
         one_step()
     torch.cuda.synchronize()
     steps = 80
