@@ -761,13 +761,13 @@ extern "C" int raae_grad_materialize(const raae_grad_t* go, int B, int C, int L,
 
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? (int)strtol(e, nullptr, 0) : dflt; }
 // Which block shapes run their large-batch (`BIG`) instance from RAAE_BIG_ROWS rows on: bit k = block shape k of
-// raae_block_shapes.inc, bit 7 = the generic instance.  Measured per kernel alone at 4096 rows (bench.py
-// --roofline-detail, us, BIG / plain): the 16-byte paths pay for the 64- and 256-point rows of shapes 0, 5, 6 and
-// cost the short rows their occupancy (190 against 80 registers) -- phase B backward of decoder block 1 75 / 31,
-// of decoder block 0 35 / 17, of encoder block 1 29 / 17, of encoder block 0 63 / 46; phase A backward of decoder
-// block 1 34 / 39-51; weight gradients of encoder block 1 59 / 45, of encoder block 0 54 / 63.  (Encoder block 0's
-// phase B backward takes its large-batch instance since the 16-byte paths start at 256 instead of 512 floats per
-// channel and group: 40 -> 31 us.)
+// raae_block_shapes.inc, bit 7 = the generic instance.  Chosen on the STEP rate at 4096 rows, not on the kernels alone:
+// the 16-byte paths pay for the 64- and 256-point rows of shapes 0, 5, 6 (phase A backward of the last decoder block
+// 55 us against 89 plain); for the short rows the BIG instances (170-200 registers) were slower alone while the small
+// shapes ran 512 workgroups (phase B backward of decoder block 1 75 us against 31), and since those shapes run 256
+// workgroups with twice the samples they are faster alone almost everywhere (that kernel 19.5 us against 28.8) -- yet
+// with all of them BIG the step is slower (272-275 steps/s against 280; 388 against 400 at 2048 rows): what a
+// main-chain kernel gains alone it takes from the weight-gradient branch running beside it.
 // Environment overrides for tuning: RAAE_BIG_MASK_{FWD_A,FWD_B,BWD_B,BWD_A,WGRAD}.
 enum { kFamFwdA, kFamFwdB, kFamBwdB, kFamBwdA, kFamWgrad };
 static const int kBigMask[5] = {env_int("RAAE_BIG_MASK_FWD_A", 0xe1), env_int("RAAE_BIG_MASK_FWD_B", 0xe1),
