@@ -16,6 +16,7 @@ the five gradient arenas are averaged over RCCL).  The line also carries:
                 this box's host cores: 1 thread + anomaly detection on, as the reference ships
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -156,6 +157,15 @@ def spawn_ranks(n):
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
+def quiet_gc():
+    """Everything allocated so far (modules, plans, captured graphs) moves to the permanent generation: a full
+    collection of the cyclic garbage collector in the middle of the timed loop walks all of it and stalls the host for
+    tens of milliseconds -- longer than the queue of launched steps lasts at batch 4096 (measured in 40-step windows:
+    280 steps/s with dips to 170-250 several times per second; a third as many with the collector held off)."""
+    gc.collect()
+    gc.freeze()
+
+
 def configs2_line(args, cfg0, dev):
     """BASELINE configs[2] beside the headline: 100 k synthetic spectra, batch 4096 -- the regime where the conv
     kernels stop being launch-bound.  Same engine, same step; returns steps/s and the top kernels' roofline."""
@@ -182,6 +192,7 @@ def configs2_line(args, cfg0, dev):
     for _ in range(20):          # eager emission, capture, first replays -- and the clocks of a GPU that sat idle
         one_step()
     torch.cuda.synchronize()
+    quiet_gc()
     steps = 80
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -287,6 +298,7 @@ def main():
 
     for _ in range(max(args.warmup, 3)):     # >= 3: eager emission, graph capture, first replay
         one_step()
+    quiet_gc()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):

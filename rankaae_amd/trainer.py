@@ -21,6 +21,7 @@ lockstep), and only rank 0 writes ``losses.csv`` / checkpoints / ``final.pt``.
 """
 import copy
 import logging
+import gc
 import os
 import shutil
 
@@ -171,6 +172,11 @@ class Trainer:
                     eng.seek(off + self.rank * rows, global_rows)
                 prev_rows = rows
                 eng.step(rows, smooth=smooth)
+            if epoch == 1:
+                # plans, captured graphs and modules are long-lived: out of the cyclic collector's way (a full
+                # collection in the middle of an epoch stalls the host for longer than the queue of launched steps lasts)
+                gc.collect()
+                gc.freeze()
             tl = eng.losses()
             if not smooth:
                 tl["smooth"] = 0.0
