@@ -347,6 +347,8 @@ def main():
             line["epoch_inclusive"] = epoch_inclusive(cfg, spec, aux)
         if not args.no_configs2 and world == 1 and (b, args.rows) == (256, 7000):
             del eng
+            gc.unfreeze()
+            gc.collect()
             torch.cuda.empty_cache()
             line["configs2"] = configs2_line(args, cfg, dev)
         if args.cpu_budget > 0 and world == 1:

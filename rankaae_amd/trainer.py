@@ -210,6 +210,7 @@ class Trainer:
                 sch.step(combined_metric)
             if callback is not None:
                 callback(epoch, metrics)
+        gc.unfreeze()        # a worker process runs several trials: the next one must be able to collect this one's objects
         if lead:
             torch.save(self._model_dict(), f"{self.work_dir}/final.pt")
             if best_chpt_file is not None:
