@@ -60,9 +60,12 @@ def cpu_baseline(cfg, spec, aux, budget_s):
     anomaly detection off.  Bounded sample: whole steps until ``budget_s`` seconds are used."""
     from oracle import ref_train
     nthreads = torch.get_num_threads()
-    torch.set_num_threads(1)
     out = {}
-    for anomaly, share in ((True, 0.65), (False, 0.35)):
+    # legs (SURVEY 8d): (i) 1 thread + anomaly detection on = how the reference ships, (ii) 1 thread, anomaly off,
+    # (iii) all cores torch gives this process (anomaly off; the reference pins 1 thread only when interop > 2,
+    # train_sc.py:68-70)
+    for anomaly, share, threads in ((True, 0.5, 1), (False, 0.25, 1), ("all", 0.25, nthreads)):
+        torch.set_num_threads(threads)
         torch.manual_seed(1234)
         tr = ref_train.OracleTrainer(spec, aux, cfg)
         for m in (tr.encoder, tr.decoder, tr.discriminator):
@@ -70,7 +73,7 @@ def cpu_baseline(cfg, spec, aux, budget_s):
         perm = ref_train.epoch_permutation(len(tr.train_spec)).numpy()
         bs = cfg["batch_size"]
         prev = torch.is_anomaly_enabled()
-        torch.autograd.set_detect_anomaly(anomaly)
+        torch.autograd.set_detect_anomaly(anomaly is True)
         t0, n = time.perf_counter(), 0
         while True:
             rows = perm[(n % 19) * bs:(n % 19 + 1) * bs]
@@ -87,6 +90,9 @@ def cpu_baseline(cfg, spec, aux, budget_s):
     return {"value": round(v, 3), "unit": "steps/s", "cores": 1, "kind": "port",
             "sample": f"{n} steps of the same workload in {el:.1f} s, 1 thread, autograd anomaly detection on "
                       f"(as the reference ships); anomaly off: {out[False][0]:.3f} steps/s",
+            "anomaly_off": {"value": round(out[False][0], 3), "cores": 1, "steps": out[False][1]},
+            "all_cores": {"value": round(out["all"][0], 3), "threads": nthreads, "steps": out["all"][1],
+                          "note": "torch intra-op threads = torch.get_num_threads() of this process, anomaly detection off"},
             "host_cpus": os.cpu_count()}
 
 
@@ -115,20 +121,79 @@ def epoch_inclusive(cfg, spec, aux, epochs=8):
             "steps_per_epoch": steps_per_epoch, "epochs_timed": len(stamps) - 2, "ms_per_epoch": round(1e3 * dt / (len(stamps) - 2), 2)}
 
 
+def _profile(pattern):
+    """Newest committed profile file matching ``profiles/r<round>_<pattern>`` (this round's first)."""
+    for rnd in ("r3", "r2"):
+        path = os.path.join(REPO, "profiles", f"{rnd}_{pattern}")
+        if os.path.exists(path):
+            return path
+    return None
+
+
 def pmc_traffic(kernel, ae_form, b):
-    """HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC summary of THIS round's build (FETCH_SIZE
-    and WRITE_SIZE collected in separate ``--pmc`` passes of this same command and summarised by tools/pmc_summary.py
-    into profiles/r2_pmc_traffic_*.json); None when there is no summary for this workload or kernel.  Hardware
-    counters cannot be read from inside the process."""
-    path = os.path.join(REPO, "profiles", f"r2_pmc_traffic_{ae_form.lower()}_b{b}.json")
-    if not os.path.exists(path):
+    """HBM bytes per launch of the kernel FAMILY ``kernel`` (all template instances, launch-weighted) from the committed
+    rocprofv3 PMC summary (FETCH_SIZE and WRITE_SIZE collected in separate ``--pmc`` passes of this same command and
+    summarised by tools/pmc_summary.py into profiles/r*_pmc_traffic_*.json).  FETCH_SIZE is DOUBLED as
+    MI355X_MICROARCH.md prescribes for gfx950's 16-byte-per-lane streaming reads (it tallies 128-byte requests at
+    64 B); WRITE_SIZE is exact.  None when there is no summary for this workload or kernel.  Hardware counters cannot
+    be read from inside the process: this is the same command's committed profile, not a measurement of this run."""
+    path = _profile(f"pmc_traffic_{ae_form.lower()}_b{b}.json")
+    if path is None:
         return None
     with open(path) as f:
         kernels = json.load(f)["kernels"]
-    for name, k in kernels.items():
-        if name.split("<")[0] == kernel.split("<")[0]:
-            return k["hbm_bytes_raw"]
-    return None
+    fam = kernel.split("<")[0].split("[")[0]
+    k = kernels.get(fam)
+    if k is None:           # a family with one instance is stored under the instance's name
+        hits = [v for name, v in kernels.items() if name.split("<")[0] == fam]
+        n = sum(v["launches"] for v in hits)
+        if not n:
+            return None
+        k = {"hbm_bytes_fetch_doubled": sum(v["hbm_bytes_fetch_doubled"] * v["launches"] for v in hits) / n,
+             "hbm_bytes_raw": sum(v["hbm_bytes_raw"] * v["launches"] for v in hits) / n}
+    return {"hbm_bytes": int(k["hbm_bytes_fetch_doubled"]), "hbm_bytes_uncorrected": int(k["hbm_bytes_raw"]),
+            "source": os.path.relpath(path, REPO)}
+
+
+def in_step_us(kernel, ae_form, b):
+    """Average duration of the kernel family inside the running step, from the committed ``rocprofv3 --kernel-trace
+    --stats`` summary of this command (profiles/r*_<net>_b<batch>_kernel_stats.csv), launch-weighted over the
+    template instances -- beside the probe's "alone" time (other branches of the graph share the chip at large batches)."""
+    import csv
+    path = _profile(f"{ae_form.lower()}_b{b}_kernel_stats.csv")
+    if path is None:
+        return None
+    fam = kernel.split("<")[0].split("[")[0]
+    calls = total = 0
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            name = row["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+            if name.split("<")[0].split("(")[0] == fam:
+                calls += int(row["Calls"])
+                total += int(row["TotalDurationNs"])
+    return round(total / calls / 1e3, 2) if calls else None
+
+
+def annotate(roof, ae_form, b):
+    """Counter traffic and in-step duration beside every probed kernel family of a roofline block."""
+    for r in roof["top_kernels"]:
+        t = pmc_traffic(r["kernel"], ae_form, b)
+        r["traffic"] = t["hbm_bytes"] if t else None
+        if t:
+            r["traffic_over_algorithmic"] = round(t["hbm_bytes"] / r["algorithmic_bytes_per_launch"], 3)
+            r["traffic_source"] = t["source"]
+        us = in_step_us(r["kernel"], ae_form, b)
+        r["in_step_launch_us"] = us
+        if us:
+            r["frac_in_step"] = round(r["algorithmic_bytes_per_launch"] / (us * 1e-6) / 1e9 / roof["peak"], 5)
+    lead = roof["top_kernels"][0]
+    roof["traffic"] = lead["traffic"]
+    roof["traffic_over_algorithmic"] = lead.get("traffic_over_algorithmic")
+    roof["in_step_launch_us"] = lead["in_step_launch_us"]
+    roof["frac_in_step"] = lead.get("frac_in_step")
+    roof["traffic_note"] = ("traffic = FETCH_SIZE x 2 + WRITE_SIZE per launch of the kernel family, from the committed "
+                            "rocprofv3 --pmc passes of this command; in_step_launch_us from its committed --kernel-trace "
+                            "--stats summary (profiles/); achieved / frac use the HIP-event time of this run, kernel alone")
 
 
 def cpu_calibration(ae_form):
@@ -193,20 +258,27 @@ def configs2_line(args, cfg0, dev):
         one_step()
     torch.cuda.synchronize()
     quiet_gc()
-    steps = 80
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        one_step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    windows, per = 6, 40         # six 40-step windows: min / median / max instead of one figure
+    rates = []
+    t_all = time.perf_counter()
+    for _ in range(windows):
+        t0 = time.perf_counter()
+        for _ in range(per):
+            one_step()
+        torch.cuda.synchronize()
+        rates.append(per / (time.perf_counter() - t0))
+    dt = time.perf_counter() - t_all
+    steps = windows * per
+    rates.sort()
+    med = 0.5 * (rates[windows // 2 - 1] + rates[windows // 2])
     out = {"workload": f"BASELINE configs[2]: {rows}x{cfg['dim_in']} synthetic spectra (train split {n_train}), batch {b}, "
-                       f"ae_form={cfg['ae_form']}", "value": round(steps / dt, 2), "unit": "steps/s",
-           "spectra_per_s": round(steps * b / dt), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps}
+                       f"ae_form={cfg['ae_form']}", "value": round(med, 2), "unit": "steps/s",
+           "windows": {"n": windows, "steps_each": per, "min": round(rates[0], 2), "median": round(med, 2),
+                       "max": round(rates[-1], 2), "all_windows_together": round(steps / dt, 2)},
+           "spectra_per_s": round(med * b), "ms_per_step": round(1e3 / med, 3), "steps": steps}
     if not args.no_roofline:
         out["roofline"] = eng.roofline_probe(b, HBM_PEAK_GBS, reps=2)
-        for r in out["roofline"]["top_kernels"]:
-            r["traffic"] = pmc_traffic(r["kernel"], cfg["ae_form"], b)
-        out["roofline"]["traffic"] = out["roofline"]["top_kernels"][0]["traffic"]
+        annotate(out["roofline"], cfg["ae_form"], b)
     return out
 
 
@@ -337,9 +409,7 @@ def main():
         # collectives the other ranks never join, and the contract asks for the CPU baseline at N = 1
         if not args.no_roofline and world == 1:
             line["roofline"] = eng.roofline_probe(b, HBM_PEAK_GBS, detail=args.roofline_detail)
-            for r in line["roofline"]["top_kernels"]:
-                r["traffic"] = pmc_traffic(r["kernel"], cfg["ae_form"], b)
-            line["roofline"]["traffic"] = line["roofline"]["top_kernels"][0]["traffic"]
+            annotate(line["roofline"], cfg["ae_form"], b)
             if b < 1024:
                 line["roofline"]["note"] = ("this batch is launch/latency bound (SURVEY 8d): every kernel moves <= 2.5 MB; "
                                             "the HBM-bound regime is the configs2 sub-run below")

@@ -38,6 +38,17 @@ typedef struct {
     int update_running;       /* exactly one consumer of a BN layer per forward sets this */
 } raae_bn_t;
 
+/* Dropout multipliers generated inside the consuming kernel (rng_mode "philox", no tape read): element e of the slot is
+ * kept iff hash(e + offset; seed, step) < keep * 2^32 and then scales by 1/keep -- the same function raae_rng_fill
+ * evaluates for tape-resident slots, so both forms of a slot are bit-identical (nn.Dropout of the reference draws from
+ * the global CPU generator instead: sc/clustering/model.py:337,351,360,526,545; parity mode keeps the host tape).
+ * state == NULL: disabled (the consumer reads its `mask` tensor, or applies none). */
+typedef struct {
+    const unsigned long long* state;   /* device: [0] step counter (raae_step_tick / raae_step_begin), [1] seed */
+    unsigned offset;                   /* position of the slot's element 0 in the numbering of all dropout elements of a step */
+    float keep;                        /* 1 - p */
+} raae_maskgen_t;
+
 /* ---- input transform applied while loading a dense layer's input ---- */
 enum { RAAE_IN_NONE = 0, RAAE_IN_PRELU_BN_DROP = 1, RAAE_IN_PRELU_DROP = 2 };
 /* ---- what the dense layer's output feeds ---- */
@@ -70,6 +81,9 @@ typedef struct {
     const float* x; int B, K, in_kind; const float* slope; int has_bn; raae_bn_t bn; const float* mask;
     const float* w; const float* bias; int N; float* z; int out_kind; const float* out_slope; double* out_partials;
     int storage;          /* RAAE_ST_* bits: which tensors are stored as bf16 (0: all fp32) */
+    float mask_scale;     /* RAAE_ST_MASK: the bf16 mask holds {0, 1} and is multiplied by this fp32 1/(1-p) (a bf16
+                             1/(1-p) would bias every activation by -0.16 %); 0 is read as 1 */
+    raae_maskgen_t gen;   /* gen.state != NULL: dropout multipliers generated in the kernel, `mask` must be NULL */
 } raae_dense_fwd_t;
 int raae_dense_fwd2(const raae_dense_fwd_t* p, const raae_dense_fwd_t* q, int* nparts_p, int* nparts_q, void* stream);
 
@@ -118,6 +132,16 @@ int raae_dense_bwd_st(const float* g, int g_kind, const double* g_partials, int 
                    const float* mask, const float* w,
                    float* dw, float* db, float* dslope, long slab_stride, int* nslab,
                    float* dx, double* dx_partials, int storage, void* stream);
+
+/* struct form (the arguments of raae_dense_bwd_st + in-kernel dropout multipliers) */
+typedef struct {
+    const float* g; int g_kind; const double* g_partials; int g_nparts; const float* zout; const float* out_slope;
+    int has_out_bn; raae_bn_t out_bn; int B, N;
+    const float* x; int K, in_kind; const float* slope; int has_bn; raae_bn_t bn; const float* mask; const float* w;
+    float* dw; float* db; float* dslope; long slab_stride; float* dx; double* dx_partials;
+    int storage; float mask_scale; raae_maskgen_t gen;
+} raae_dense_bwd_t;
+int raae_dense_bwd_s(const raae_dense_bwd_t* p, int* nslab, void* stream);
 
 /* Final BatchNorm1d(nstyle, affine=False) of both encoders (model.py:284,366):
  * styles = BN(z).  Backward: dz from dstyles (torch batch_norm backward, train mode). */
@@ -415,10 +439,12 @@ int raae_slab_reduce(const float* g_slabs, long slab_stride, const unsigned shor
 int raae_step_tick(int* steps, int n, unsigned mask, unsigned long long* rng_counter, int* cursor, int cursor_inc,
                    void* stream);
 
-/* Philox4x32-10 fill of the per-step random tape (speed mode; parity mode uploads a tape drawn
- * on the host in the reference's order).  seg_desc (device): [nseg][4] ints
- * {offset, count, kind (0 = N(0,1), 1 = dropout scale {0,1/keep}), 0}, offsets multiples of 4,
- * ascending; seg_scale (device) [nseg] = keep probability for kind 1; counter (device) = step index. */
+/* Fill of the per-step random tape (speed mode; parity mode uploads a tape drawn on the host in the reference's order,
+ * SURVEY.md 3.4).  seg_desc (device): [nseg][4] ints {offset, count, kind, hash offset}, offsets multiples of 4,
+ * ascending; kind 0 = N(0,1) (Philox4x32-10 + Box-Muller), 1 = dropout scale {0, 1/keep}, 2 = keep flags {0, 1} as
+ * bf16 (two per float); kinds 1 and 2 evaluate the counter-based hash of raae_maskgen_t at hash offset + element
+ * index, so a slot has the same values on the tape as when its consumer generates it; seg_scale (device) [nseg] =
+ * keep probability; counter (device) = step index. */
 int raae_rng_fill(float* tape, const int* seg_desc, const float* seg_scale, int nseg, long total,
                   unsigned long long seed, const unsigned long long* counter, void* stream);
 
@@ -434,7 +460,7 @@ int raae_event_destroy(void* ev);
 int raae_stream_sync(void* stream);
 const char* raae_error_string(int code);
 int raae_device_info(int* cu_count, int* lds_bytes, char* name, int name_len);
-#define RAAE_ABI_VERSION 11
+#define RAAE_ABI_VERSION 12
 int raae_abi_version(void);
 /* First 16 hex digits of sha256 over include/rankaae_hip.h + csrc/raae_*.{h,inc,hip} at build time
  * (build.sh); the Python loader recomputes it and refuses a library built from other sources. */

@@ -436,3 +436,15 @@ def derived_bounds(cfg, model_seed, spec, aux, keys, modes=(1, -1, 2, 3, 11, 12,
     base = first_step(cfg, model_seed, spec, aux, 0, alpha_)
     pert = [first_step(cfg, model_seed, spec, aux, m, alpha_) for m in modes]
     return base, {k: 3.0 * max(abs(p[k] - base[k]) for p in pert) + 1e-4 * abs(base[k]) + 1e-7 for k in keys}
+
+
+CONSTRAINING_REL = 0.05
+
+
+def constraining(base, bound, keys, rel=CONSTRAINING_REL):
+    """``(tight, loose)``: the keys whose derived bound is at most ``rel`` of the oracle's value, and the others.  A
+    derived bound of 30-50 % (the mutual-information loss of the dense networks after Adam's first sign-like updates)
+    is an honest statement of the step's sensitivity but asserts nothing: such keys are REPORTED as not constraining
+    and left to the teacher-forced (P2) and frozen-weight (P4) comparisons, which pin those phases to 1e-4."""
+    tight = [k for k in keys if bound[k] <= rel * abs(base[k]) + 1e-7]
+    return tight, [k for k in keys if k not in tight]

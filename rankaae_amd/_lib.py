@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librankaae_hip.so")
 
 RAAE_MAX_PARTS = 512
-ABI_VERSION = 11
+ABI_VERSION = 12
 IN_NONE, IN_PRELU_BN_DROP, IN_PRELU_DROP = 0, 1, 2
 OUT_RAW, OUT_STATS_PRELU, OUT_STATS_RAW, OUT_SOFTPLUS, OUT_RELU = 0, 1, 2, 3, 4
 G_DIRECT, G_SOFTPLUS, G_PRELU_BN, G_PRELU, G_RELU = 0, 1, 2, 3, 4
@@ -22,12 +22,28 @@ class BnT(C.Structure):
                 ("momentum", C.c_float), ("eps", C.c_float), ("update_running", C.c_int)]
 
 
+class MaskGenT(C.Structure):
+    """``raae_maskgen_t``"""
+    _fields_ = [("state", C.c_void_p), ("offset", C.c_uint), ("keep", C.c_float)]
+
+
 class DenseFwdT(C.Structure):
     """``raae_dense_fwd_t``"""
     _fields_ = [("x", C.c_void_p), ("B", C.c_int), ("K", C.c_int), ("in_kind", C.c_int), ("slope", C.c_void_p),
                 ("has_bn", C.c_int), ("bn", BnT), ("mask", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p),
                 ("N", C.c_int), ("z", C.c_void_p), ("out_kind", C.c_int), ("out_slope", C.c_void_p),
-                ("out_partials", C.c_void_p), ("storage", C.c_int)]
+                ("out_partials", C.c_void_p), ("storage", C.c_int), ("mask_scale", C.c_float), ("gen", MaskGenT)]
+
+
+class DenseBwdT(C.Structure):
+    """``raae_dense_bwd_t``"""
+    _fields_ = [("g", C.c_void_p), ("g_kind", C.c_int), ("g_partials", C.c_void_p), ("g_nparts", C.c_int),
+                ("zout", C.c_void_p), ("out_slope", C.c_void_p), ("has_out_bn", C.c_int), ("out_bn", BnT),
+                ("B", C.c_int), ("N", C.c_int), ("x", C.c_void_p), ("K", C.c_int), ("in_kind", C.c_int),
+                ("slope", C.c_void_p), ("has_bn", C.c_int), ("bn", BnT), ("mask", C.c_void_p), ("w", C.c_void_p),
+                ("dw", C.c_void_p), ("db", C.c_void_p), ("dslope", C.c_void_p), ("slab_stride", C.c_long),
+                ("dx", C.c_void_p), ("dx_partials", C.c_void_p), ("storage", C.c_int), ("mask_scale", C.c_float),
+                ("gen", MaskGenT)]
 
 
 ST_X, ST_MASK, ST_Z = 1, 2, 4        # RAAE_ST_*: bf16 storage bits of the dense kernels
@@ -143,6 +159,7 @@ SIGNATURES = {
                             _P, _P, _P, _L, _PI, _P, _P, _P]),
     "raae_dense_bwd_st": (_I, [_P, _I, _P, _I, _P, _P, _PB, _I, _I, _P, _I, _I, _P, _PB, _P, _P,
                                _P, _P, _P, _L, _PI, _P, _P, _I, _P]),
+    "raae_dense_bwd_s": (_I, [C.POINTER(DenseBwdT), _PI, _P]),
     "raae_style_bn_fwd": (_I, [_P, _I, _I, _PB, _P, _P]),
     "raae_style_bn_bwd": (_I, [_P, _P, _I, _I, _PB, _F, _P, _P]),
     "raae_rank_loss_work_bytes": (_L, [_I, _I]),

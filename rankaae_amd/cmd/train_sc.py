@@ -43,11 +43,21 @@ def run_training(job_number, work_dir, train_config, verbose, data_file, timeout
     logger.info(f"Training started for trial {job_number + 1}.")
     trainer = Trainer.from_data(data_file, igpu=igpu, verbose=verbose, work_dir=work_dir,
                                 config_parameters=train_config, logger=logger, loss_logger=loss_logger)
-    signal.signal(signal.SIGALRM, timeout_handler)
-    signal.alarm(int(timeout_hours * 3600))
-    metrics = trainer.train()
+    trainer.freeze_gc = bool(train_config.get("freeze_gc", True))   # a dedicated training process: collector held off
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # data parallel: the rank whose alarm fires must not leave the others waiting in a collective -- it asks the
+        # trainer to stop, and every rank raises the reference's exception together at the next epoch boundary
+        signal.signal(signal.SIGALRM, lambda signum, frame: trainer.request_stop("Training Overtime!"))
+    else:
+        signal.signal(signal.SIGALRM, timeout_handler)
+    # (signal.setitimer: fractional hours work too -- signal.alarm(int(...)) of the reference rounds a sub-second
+    # timeout to "never"; whole seconds behave identically)
+    signal.setitimer(signal.ITIMER_REAL, max(0.0, float(timeout_hours) * 3600.0))
+    try:
+        metrics = trainer.train()
+    finally:
+        signal.setitimer(signal.ITIMER_REAL, 0.0)
     logger.info(metrics)
-    signal.alarm(0)
     time_used = time.time() - start
     logger.info(f"Training finished. Time used: {time_used:.2f}s.\n\n")
     return metrics, time_used

@@ -293,4 +293,138 @@ __device__ __forceinline__ void stat_jobs(const StatJob (&jobs)[N], bool is_bloc
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// ---- dropout multipliers from a counter-based hash (rng_mode "philox") ---------------------------------------------
+// A dropout multiplier carries ONE bit.  Instead of a Philox block per four multipliers written to a fp32 tape and read
+// back by every consumer (146 MB per step at 4096 rows), element e of the step's random tape is
+//     keep(e) = lowbias32(lowbias32(e + k1) ^ k2) < keep * 2^32,      (k1, k2) = f(seed, step counter)
+// (lowbias32: C. Wellons' 2-multiply avalanche hash, bias 0.17; two rounds keyed differently decorrelate the steps).
+// ~12 integer instructions per element, any access granularity, so a consumer regenerates its multipliers while it
+// loads the tensor they scale.  raae_rng_fill evaluates THE SAME function for the slots that still live on the tape
+// (consumers without in-kernel generation, `inline_masks: false`): tape and in-kernel masks are bit-identical
+// (tests/test_engine_gpu.py::test_inline_masks_equal_tape_masks).  Gaussian slots stay Philox4x32-10 + Box-Muller.
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+struct MaskGen { uint32_t k1, k2, thr, off; float inv; };
+__device__ __forceinline__ MaskGen mask_gen_make(unsigned long long seed, unsigned long long ctr, uint32_t off, float keep) {
+    MaskGen m;
+    m.k1 = lowbias32((uint32_t)seed ^ lowbias32((uint32_t)ctr + 0x9E3779B9u));
+    m.k2 = lowbias32((uint32_t)(seed >> 32) + 0x85EBCA6Bu + lowbias32((uint32_t)(ctr >> 32) ^ m.k1));
+    const double t = (double)keep * 4294967296.0;
+    m.thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+    m.inv = 1.f / keep;
+    m.off = off;
+    return m;
+}
+// state (device): [0] = step counter (advanced once per step), [1] = seed
+__device__ __forceinline__ MaskGen mask_gen_from(const raae_maskgen_t& g) {
+    return mask_gen_make(g.state[1], g.state[0], g.offset, g.keep);
+}
+__device__ __forceinline__ bool mask_keep(const MaskGen& m, uint32_t e) {     // e: element index inside the slot
+    return lowbias32(lowbias32(e + m.off + m.k1) ^ m.k2) < m.thr;
+}
+__device__ __forceinline__ float mask_val(const MaskGen& m, uint32_t e) { return mask_keep(m, e) ? m.inv : 0.f; }
+__device__ __forceinline__ float4 mask_val4(const MaskGen& m, uint32_t e) {
+    return make_float4(mask_val(m, e), mask_val(m, e + 1), mask_val(m, e + 2), mask_val(m, e + 3));
+}
+
+// ---- one to three BatchNorm statistic reductions spread over ALL FOUR waves of a 256-thread block -------------------
+// (stat_jobs gives each statistic one wave: right for the conv kernels with their 4-8 channels and several jobs; a
+// dense layer has 64 channels = one per lane, so a single wave walked every partial row: 32 dependent trips at 256
+// rows -- 15 of the 20 us of a dense forward at 4096 rows.)  Wave w takes row phases w*J .. w*J + J - 1 of 4J
+// (J = 64 / pow2(C) lanes share a channel); the first batch of every job's loads is issued before any is used; the
+// four waves' sums meet in LDS in wave order (fixed order => deterministic).  C <= 64.  All threads call it; ends
+// with a barrier.
+template <int N>
+__device__ __forceinline__ void stat_jobs_wide(const StatJob (&jobs)[N], bool is_block0) {
+    __shared__ double2 scr[N][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int D = N >= 3 ? 4 : 8;                 // loads in flight per job and lane
+    double2 v[N][D];
+    int cpv[N], cv[N], phv[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        const StatJob& jb = jobs[n];
+        if (jb.kind == 2 || jb.partials == nullptr) continue;
+        int cp = 1;
+        while (cp < jb.C) cp <<= 1;
+        const int J = 64 / cp, c = lane & (cp - 1);
+        cpv[n] = cp; cv[n] = c; phv[n] = wave * J + lane / cp;
+        const double2* p = reinterpret_cast<const double2*>(jb.partials) + (c < jb.C ? c : 0);
+        const int last = jb.nparts - 1, nph = 4 * J;
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const int r = phv[n] + u * nph;
+            v[n][u] = p[(size_t)(r < last ? r : last) * jb.C];
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        const StatJob& jb = jobs[n];
+        if (jb.kind == 2 || jb.partials == nullptr) continue;
+        const int cp = cpv[n], c = cv[n], nph = 4 * (64 / cp), last = jb.nparts - 1;
+        double s = 0.0, q = 0.0;
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const bool ok = phv[n] + u * nph <= last;
+            s += ok ? v[n][u].x : 0.0; q += ok ? v[n][u].y : 0.0;
+        }
+        const double2* p = reinterpret_cast<const double2*>(jb.partials) + (c < jb.C ? c : 0);
+        for (int i = phv[n] + D * nph; i < jb.nparts; i += 8 * nph) {
+            double2 w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = i + u * nph;
+                w[u] = p[(size_t)(r < last ? r : last) * jb.C];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool ok = i + u * nph <= last;
+                s += ok ? w[u].x : 0.0; q += ok ? w[u].y : 0.0;
+            }
+        }
+        if (c >= jb.C) { s = 0.0; q = 0.0; }
+        for (int o = 32; o >= cp; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+        if (lane < jb.C) scr[n][wave][lane] = make_double2(s, q);
+    }
+    __syncthreads();
+    // thread (n, c) = (tid / 64, tid % 64) finishes statistic c of job n  (compile-time n: a runtime index into the
+    // job array would put it in scratch memory)
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        if (n == wave) {
+            const StatJob& jb = jobs[n];
+            if (jb.kind != 2 && lane < jb.C) {
+                if (jb.partials == nullptr) {          // eval mode: running statistics
+                    jb.o1[lane] = jb.rm[lane];
+                    jb.o2[lane] = 1.0f / sqrtf(jb.rv[lane] + jb.eps);
+                } else {
+                    double s = 0.0, q = 0.0;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) { s += scr[n][w][lane].x; q += scr[n][w][lane].y; }
+                    const double inv = 1.0 / (double)jb.count;
+                    if (jb.kind == 0) {
+                        const double mean = s * inv;
+                        double var = q * inv - mean * mean;
+                        if (var < 0.0) var = 0.0;
+                        jb.o1[lane] = (float)mean;
+                        jb.o2[lane] = (float)(1.0 / sqrt(var + (double)jb.eps));
+                        if (is_block0 && jb.update && jb.rm != nullptr) {
+                            const double n_ = (double)jb.count;
+                            const double unb = n_ > 1.0 ? var * n_ / (n_ - 1.0) : var;
+                            jb.rm[lane] = (float)((1.0 - jb.momentum) * (double)jb.rm[lane] + jb.momentum * mean);
+                            jb.rv[lane] = (float)((1.0 - jb.momentum) * (double)jb.rv[lane] + jb.momentum * unb);
+                        }
+                    } else {
+                        jb.o1[lane] = (float)(s * inv);
+                        jb.o2[lane] = (float)(q * inv);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
 }  // namespace raae

@@ -20,15 +20,16 @@ using raae::prelu;
 struct DenseFwdArgs {
     const float* x; int B; int K; int in_kind; const float* slope; raae_bn_t bn; const float* mask;
     const float* w; const float* bias; int N; float* z; int out_kind; const float* out_slope;
-    double* out_partials; int pitch; int storage;
+    double* out_partials; int pitch; int storage; float mask_scale; raae_maskgen_t gen;
 };
 
 // ---- bf16 STORAGE of activations and dropout multipliers (`precision: bf16`, BASELINE configs[4]) ----------------
 // RAAE_ST_X / _MASK / _Z: the layer input / its dropout multipliers / the layer's raw output live in memory as bf16
 // (the pointers are still typed float*).  Everything is converted to fp32 on load and all arithmetic, statistics and
 // accumulators stay fp32 / double; the output is rounded to bf16 (round to nearest even: v_cvt_pk_bf16_f32) BEFORE its
-// BatchNorm statistics are taken, so that the statistics describe the values the next layer will read.
-// With storage == 0 no instruction of the fp32 path changes.
+// BatchNorm statistics are taken, so that the statistics describe the values the next layer will read.  A bf16 mask
+// holds {0, 1}; the fp32 1/(1-p) multiplies it here (mask_scale).  With storage == 0 no instruction of the fp32 path
+// changes.
 __device__ __forceinline__ float bf16_at(const float* p, size_t i) {
     return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(p)[i] << 16);
 }
@@ -52,50 +53,108 @@ __device__ __forceinline__ float in_transform(float v, int k, int in_kind, const
     return v;
 }
 
-// Stage a 16-row tile of the layer input into LDS (transform applied, zero padded to K4 columns).
-// Vector path (K % 4 == 0): one float4 per thread per pass, no integer division in the loop.
-__device__ __forceinline__ void stage_rows(float* Xs, int pitch, const float* x, const float* mask, int row0, int B,
-                                           int K, int K4, int in_kind, const float* s_slope, const float* s_mean,
-                                           const float* s_rstd, int storage = 0) {
-    const int tid = threadIdx.x;
-    const bool xb = (storage & RAAE_ST_X) != 0, mb = (storage & RAAE_ST_MASK) != 0;
-    if ((K & 3) == 0) {
-        const int kq = K >> 2;                       // float4s per row
-        int r = tid / kq, c4 = tid - r * kq;
-        const int dr = 256 / kq, dc = 256 - dr * kq;
-        for (; r < 16; ) {
-            const int row = row0 + r, k = c4 << 2;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < B) {
-                v = xb ? bf16x4_at(x, (size_t)row * K + k) : *reinterpret_cast<const float4*>(x + (size_t)row * K + k);
-                v.x = in_transform(v.x, k, in_kind, s_slope, s_mean, s_rstd);
-                v.y = in_transform(v.y, k + 1, in_kind, s_slope, s_mean, s_rstd);
-                v.z = in_transform(v.z, k + 2, in_kind, s_slope, s_mean, s_rstd);
-                v.w = in_transform(v.w, k + 3, in_kind, s_slope, s_mean, s_rstd);
-                if (in_kind != RAAE_IN_NONE && mask) {
-                    const float4 m = mb ? bf16x4_at(mask, (size_t)row * K + k)
-                                        : *reinterpret_cast<const float4*>(mask + (size_t)row * K + k);
-                    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
-                }
-            }
-            float2* dst = reinterpret_cast<float2*>(Xs + r * pitch + k);     // pitch even => 8-B aligned
-            dst[0] = make_float2(v.x, v.y);
-            dst[1] = make_float2(v.z, v.w);
-            r += dr; c4 += dc;
-            if (c4 >= kq) { c4 -= kq; ++r; }
+// Where a layer's dropout multipliers come from: a tensor (fp32 {0, 1/keep} or bf16 {0, 1} x scale), or the in-kernel
+// hash generator (raae_common.h), or nowhere.
+struct MaskSrc {
+    const float* ptr; bool bf; float scale; bool gen; raae::MaskGen g;
+    __device__ __forceinline__ bool any() const { return gen || ptr != nullptr; }
+    __device__ __forceinline__ float4 at4(size_t o) const {        // o a multiple of 4
+        if (gen) return raae::mask_val4(g, (uint32_t)o);
+        if (bf) { const float4 m = bf16x4_at(ptr, o); return make_float4(m.x * scale, m.y * scale, m.z * scale, m.w * scale); }
+        return *reinterpret_cast<const float4*>(ptr + o);
+    }
+    __device__ __forceinline__ float at(size_t o) const {
+        if (gen) return raae::mask_val(g, (uint32_t)o);
+        return bf ? bf16_at(ptr, o) * scale : ptr[o];
+    }
+};
+__device__ __forceinline__ MaskSrc mask_src(const float* mask, int in_kind, int storage, float scale, const raae_maskgen_t& gen) {
+    MaskSrc m;
+    m.ptr = in_kind != RAAE_IN_NONE ? mask : nullptr;
+    m.bf = (storage & RAAE_ST_MASK) != 0;
+    m.scale = scale != 0.f ? scale : 1.f;
+    m.gen = in_kind != RAAE_IN_NONE && gen.state != nullptr;
+    if (m.gen) m.g = raae::mask_gen_from(gen);
+    return m;
+}
+
+// One 16-row tile of a layer input as NV float4 per thread (K % 4 == 0): thread t holds float4 number t + 256 u of the
+// tile, i.e. (row f / kq, columns 4 (f % kq) ..).  The raw values and their dropout multipliers are LOADED here and
+// transformed / stored to LDS later, so that the loads of a tile are in flight during the statistic prologue (first
+// tile) or the previous tile's matrix work (following tiles).
+template <int NV>
+struct RawTile { float4 x[NV]; float4 m[NV]; };
+
+template <int NV>
+__device__ __forceinline__ void tile_coords(int kq, int (&rr)[NV], int (&cc)[NV]) {
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int f = threadIdx.x + 256 * u;
+        rr[u] = f / kq;
+        cc[u] = (f - rr[u] * kq) << 2;
+    }
+}
+// (K: the row stride of x and of the multipliers' numbering; k0: first column of this workgroup's slice of the row)
+template <int NV>
+__device__ __forceinline__ void tile_load(RawTile<NV>& t, const int (&rr)[NV], const int (&cc)[NV], const float* x, bool xb,
+                                          const MaskSrc& ms, int row0, int B, int K, int k0 = 0) {
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int row = row0 + rr[u];
+        t.x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        t.m[u] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (rr[u] < 16 && row < B) {
+            const size_t o = (size_t)row * K + k0 + cc[u];
+            t.x[u] = xb ? bf16x4_at(x, o) : *reinterpret_cast<const float4*>(x + o);
+            if (ms.any()) t.m[u] = ms.at4(o);
         }
-    } else {
-        for (int idx = tid; idx < 16 * K4; idx += 256) {
-            const int r = idx / K4, k = idx - r * K4;
-            const int row = row0 + r;
-            float v = 0.f;
-            if (row < B && k < K) {
-                const size_t o = (size_t)row * K + k;
-                v = in_transform(xb ? bf16_at(x, o) : x[o], k, in_kind, s_slope, s_mean, s_rstd);
-                if (in_kind != RAAE_IN_NONE && mask) v *= mb ? bf16_at(mask, o) : mask[o];
-            }
-            Xs[r * pitch + k] = v;
+    }
+}
+// transform -> Xs (x * mask); optionally the pre-dropout value -> Ys and the multiplier -> Ms (backward epilogue)
+template <int NV>
+__device__ __forceinline__ void tile_store(const RawTile<NV>& t, const int (&rr)[NV], const int (&cc)[NV], float* Xs, float* Ys,
+                                           float* Ms, int pitch, int in_kind, const float* s_slope, const float* s_mean,
+                                           const float* s_rstd) {
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        if (rr[u] >= 16) continue;
+        const int k = cc[u];
+        float4 v = t.x[u];
+        v.x = in_transform(v.x, k, in_kind, s_slope, s_mean, s_rstd);
+        v.y = in_transform(v.y, k + 1, in_kind, s_slope, s_mean, s_rstd);
+        v.z = in_transform(v.z, k + 2, in_kind, s_slope, s_mean, s_rstd);
+        v.w = in_transform(v.w, k + 3, in_kind, s_slope, s_mean, s_rstd);
+        const float4 m = t.m[u];
+        const int o = rr[u] * pitch + k;               // pitch even => 8-byte aligned
+        if (Ys != nullptr) {
+            reinterpret_cast<float2*>(Ys + o)[0] = make_float2(v.x, v.y);
+            reinterpret_cast<float2*>(Ys + o)[1] = make_float2(v.z, v.w);
         }
+        if (Ms != nullptr) {
+            reinterpret_cast<float2*>(Ms + o)[0] = make_float2(m.x, m.y);
+            reinterpret_cast<float2*>(Ms + o)[1] = make_float2(m.z, m.w);
+        }
+        reinterpret_cast<float2*>(Xs + o)[0] = make_float2(v.x * m.x, v.y * m.y);
+        reinterpret_cast<float2*>(Xs + o)[1] = make_float2(v.z * m.z, v.w * m.w);
+    }
+}
+
+// The same for any K (a decoder's first layer has K = nstyle = 6): element by element, zero padded to KP columns.
+__device__ __forceinline__ void stage_rows_scalar(float* Xs, float* Ys, float* Ms, int pitch, const float* x, bool xb,
+                                                  const MaskSrc& ms, int row0, int B, int K, int KP, int in_kind,
+                                                  const float* s_slope, const float* s_mean, const float* s_rstd) {
+    for (int idx = threadIdx.x; idx < 16 * KP; idx += 256) {
+        const int r = idx / KP, k = idx - r * KP;
+        const int row = row0 + r;
+        float v = 0.f, m = 1.f;
+        if (row < B && k < K) {
+            const size_t o = (size_t)row * K + k;
+            v = in_transform(xb ? bf16_at(x, o) : x[o], k, in_kind, s_slope, s_mean, s_rstd);
+            if (ms.any()) m = ms.at(o);
+        }
+        if (Ys != nullptr) Ys[r * pitch + k] = v;
+        if (Ms != nullptr) Ms[r * pitch + k] = m;
+        Xs[r * pitch + k] = v * m;
     }
 }
 
@@ -107,6 +166,7 @@ __device__ __forceinline__ void stage_rows(float* Xs, int pitch, const float* x,
 template <int KQ, bool ST = false>
 __device__ __forceinline__ void dense_fwd_body(const DenseFwdArgs& a, const int bx, const int by, const int gx, float* smem) {
     const int st = ST ? a.storage : 0;
+    constexpr int NV = KQ >= 64 ? KQ / 16 : 1;       // float4s per thread of a 16-row tile (K <= 4 KQ)
     const int K4 = (a.K + 3) & ~3;
     float* s_mean = smem;
     float* s_rstd = s_mean + K4;
@@ -114,6 +174,8 @@ __device__ __forceinline__ void dense_fwd_body(const DenseFwdArgs& a, const int 
     float* Xs = s_slope + K4;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int col = by * 64 + wv * 16 + (lane & 15);
+    const bool vec = (a.K & 3) == 0, xb = (st & RAAE_ST_X) != 0;
+    const int ntiles = (a.B + 15) >> 4;
 
     float wreg[KQ];
 #pragma unroll
@@ -121,10 +183,18 @@ __device__ __forceinline__ void dense_fwd_body(const DenseFwdArgs& a, const int 
         const int k = 4 * q + (lane >> 4);
         wreg[q] = (col < a.N && k < a.K) ? a.w[(size_t)col * a.K + k] : 0.f;
     }
+    const MaskSrc ms = mask_src(a.mask, a.in_kind, st, a.mask_scale, a.gen);
+    // the first tile's raw input and multipliers: in flight during the statistic prologue
+    int rr[NV], cc[NV];
+    RawTile<NV> raw;
+    if (vec) {
+        tile_coords<NV>(a.K >> 2, rr, cc);
+        tile_load<NV>(raw, rr, cc, a.x, xb, ms, bx << 4, a.B, a.K);
+    }
     if (a.in_kind == RAAE_IN_PRELU_BN_DROP) {
-        if (a.K <= 64) {            // wave-per-statistic pass (raae_common.h), as in the conv kernels
+        if (a.K <= 64) {            // all four waves sweep the partial rows (raae_common.h)
             const raae::StatJob jobs[1] = {raae::stat_job_bn(a.bn, a.K, s_mean, s_rstd, true)};
-            raae::stat_jobs<1>(jobs, bx == 0 && by == 0);
+            raae::stat_jobs_wide<1>(jobs, bx == 0 && by == 0);
         } else {
             raae::bn_prologue(a.bn, a.K, s_mean, s_rstd, bx == 0 && by == 0);
         }
@@ -133,7 +203,6 @@ __device__ __forceinline__ void dense_fwd_body(const DenseFwdArgs& a, const int 
         for (int k = tid; k < a.K; k += 256) s_slope[k] = a.slope[k];
     __syncthreads();
 
-    const int ntiles = (a.B + 15) >> 4;
     const float bias = (col < a.N) ? a.bias[col] : 0.f;
     const float oslope = (a.out_kind == RAAE_OUT_STATS_PRELU && col < a.N) ? a.out_slope[col] : 1.f;
     double s_acc = 0.0, q_acc = 0.0;
@@ -141,7 +210,13 @@ __device__ __forceinline__ void dense_fwd_body(const DenseFwdArgs& a, const int 
 
     for (int tile = bx; tile < ntiles; tile += gx) {
         const int row0 = tile << 4;
-        stage_rows(Xs, a.pitch, a.x, a.mask, row0, a.B, a.K, K4, a.in_kind, s_slope, s_mean, s_rstd, st);
+        if (vec) {
+            tile_store<NV>(raw, rr, cc, Xs, nullptr, nullptr, a.pitch, a.in_kind, s_slope, s_mean, s_rstd);
+            if (tile + gx < ntiles)       // the next tile's loads fly during this tile's matrix work and stores
+                tile_load<NV>(raw, rr, cc, a.x, xb, ms, (tile + gx) << 4, a.B, a.K);
+        } else {
+            stage_rows_scalar(Xs, nullptr, nullptr, a.pitch, a.x, xb, ms, row0, a.B, a.K, K4, a.in_kind, s_slope, s_mean, s_rstd);
+        }
         __syncthreads();
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -207,16 +282,35 @@ struct DenseBwdArgs {
     const float* x; int K; int in_kind; const float* slope; raae_bn_t bn; const float* mask; const float* w;
     float* dw; float* db; float* dslope; long slab_stride; float* dx; double* dx_partials;
     int pitch_g; int pitch_x; int storage;      // RAAE_ST_X: x, RAAE_ST_MASK: mask, RAAE_ST_Z: zout are bf16
+    float mask_scale; raae_maskgen_t gen;
+    int kw;       // input columns per workgroup: blockIdx.y owns columns [y kw, (y + 1) kw) of x, dW and dx (kw == K: all)
 };
 
-// TPW: 16x16 dW tiles per wave; KT4: 16-column dx tiles per wave.
+// TPW: 16x16 dW tiles per wave; KT4: 16-column dx tiles per wave (= float4s per thread of an input tile).
+// NQ: 16 -> N <= 64 (a thread owns one output column and four rows of a tile), 64 -> N <= 256, 0 -> N <= 512 (a thread
+//     owns its column(s) over all 16 rows); for NQ > 0 the W operands of the dx product (N16/4 x KT4 floats per lane)
+//     stay in registers across the row tiles.
 // LDS: o_mean[N16] o_rstd[N16] o_slope[N16] m1[N16] m2[N16] | i_mean[K16] i_rstd[K16] i_slope[K16]
-//      | Gs[16][pitch_g] | Xs[16][pitch_x] | red[2][256]
-template <int TPW, int KT4, bool ST = false>
+//      | Gs[16][pitch_g] | Xs[16][pitch_x] | Ys[16][pitch_x] | Ms[16][pitch_x] | red[2][256]
+// The raw operands of a row tile (dL/dy, the stored output, the layer input, its multipliers) are LOADED into registers
+// one tile ahead: during the statistic prologue for the first tile (one round trip instead of four dependent ones: the
+// row loop of the gradient staging used to wait for every row), during the matrix work for the following ones.
+template <int TPW, int KT4, int NQ, bool ST = false>
 __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int st = ST ? a.storage : 0;
-    const int N16 = (a.N + 15) & ~15, K16 = (a.K + 15) & ~15;
+    constexpr bool WIDE = NQ != 16;                  // N > 64
+    constexpr int H = NQ == 0 ? 2 : 1;               // column sets per thread
+    constexpr int GR = WIDE ? 16 : 4;                // rows of a tile per thread and column
+    constexpr int NV = KT4;
+    constexpr bool WREGS = NQ > 0 && KT4 * NQ <= 64;   // W operands of the dx product in registers (else: from memory)
+    // the widest shapes (512-point first / last layer) have no registers to carry a tile ahead: they load where they stage
+    constexpr bool XPRE = KT4 < 8, GPRE = NQ != 0;
+    // A first layer (K = 256 / 512 input points, no input transform) is split over blockIdx.y in slices of kw columns:
+    // more workgroups for the launch-bound batches, and a dW tile set that fits the registers (the unsplit 512-column
+    // instance spilled).  Kl: this workgroup's columns, k0: the first of them.
+    const int k0 = blockIdx.y * a.kw, Kl = a.kw;
+    const int N16 = (a.N + 15) & ~15, K16 = (Kl + 15) & ~15;
     float* o_mean = smem;
     float* o_rstd = o_mean + N16;
     float* o_slope = o_rstd + N16;
@@ -227,18 +321,68 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
     float* i_slope = i_rstd + K16;
     float* Gs = i_slope + K16;
     float* Xs = Gs + 16 * a.pitch_g;
-    float* red = Xs + 16 * a.pitch_x;
+    float* Ys = Xs + 16 * a.pitch_x;
+    float* Ms = Ys + 16 * a.pitch_x;
+    float* red = Ms + 16 * a.pitch_x;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int NT = N16 >> 4, KT = K16 >> 4;
+    const bool vec = (Kl & 3) == 0 && (a.K & 3) == 0, xb = (st & RAAE_ST_X) != 0, zb = (st & RAAE_ST_Z) != 0;
+    const bool need_y = a.dx != nullptr && a.dx_partials != nullptr;
+    const MaskSrc ms = mask_src(a.mask, a.in_kind, st, a.mask_scale, a.gen);
+    const bool need_m = a.dx != nullptr && ms.any();
+    const int ntiles = (a.B + 15) >> 4;
+
+    // ---- W operands of the dx product: registers (loads in flight during the prologue) ----
+    float wdx[WREGS ? KT4 : 1][WREGS ? NQ : 1];
+    if (WREGS && a.dx != nullptr) {
+#pragma unroll
+        for (int i = 0; i < (WREGS ? KT4 : 1); ++i) {
+            const int kcol = (wv + 4 * i) * 16 + (lane & 15);
+#pragma unroll
+            for (int u = 0; u < (WREGS ? NQ : 1); ++u) {
+                const int n = 4 * u + (lane >> 4);
+                wdx[i][u] = (kcol < Kl && n < a.N) ? a.w[(size_t)n * a.K + k0 + kcol] : 0.f;
+            }
+        }
+    }
+    // ---- the first tile's raw operands ----
+    // G: thread owns column(s) n = tid (+256) when N > 64, else n = tid % 64 with row phase tid / 64
+    const int gcol0 = WIDE ? tid : (tid & 63);
+    const int grow0 = WIDE ? 0 : (tid >> 6);
+    constexpr int grstep = WIDE ? 1 : 4;
+    float gq[H][GR], zq[H][GR];
+    auto g_load = [&](int row0) {
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const int n = gcol0 + h * 256;
+#pragma unroll
+            for (int j = 0; j < GR; ++j) {
+                const int row = row0 + grow0 + j * grstep;
+                gq[h][j] = 0.f; zq[h][j] = 0.f;
+                if (row < a.B && n < a.N) {
+                    const size_t o = (size_t)row * a.N + n;
+                    gq[h][j] = a.g[o];
+                    if (a.g_kind != RAAE_G_DIRECT) zq[h][j] = (zb && a.g_kind != RAAE_G_SOFTPLUS && a.g_kind != RAAE_G_RELU) ? bf16_at(a.zout, o) : a.zout[o];
+                }
+            }
+        }
+    };
+    int rr[NV], cc[NV];
+    RawTile<NV> raw;
+    if (GPRE) g_load(blockIdx.x << 4);
+    if (vec && XPRE) {
+        tile_coords<NV>(Kl >> 2, rr, cc);
+        tile_load<NV>(raw, rr, cc, a.x, xb, ms, blockIdx.x << 4, a.B, a.K, k0);
+    }
 
     const bool g_bn = a.g_kind == RAAE_G_PRELU_BN, i_bn = a.in_kind == RAAE_IN_PRELU_BN_DROP;
     if ((!g_bn || a.N <= 64) && (!i_bn || a.K <= 64)) {
-        // the three statistic reductions side by side, one wave each (they used to run one after the other)
+        // the three statistic reductions together, every one spread over the four waves
         const raae::StatJob jobs[3] = {
             g_bn ? raae::stat_job_bn(a.out_bn, a.N, o_mean, o_rstd, false) : raae::stat_job_none(),
             g_bn ? raae::stat_job_bwd(a.g_partials, a.g_nparts, a.N, a.out_bn.count, m1, m2) : raae::stat_job_none(),
             i_bn ? raae::stat_job_bn(a.bn, a.K, i_mean, i_rstd, false) : raae::stat_job_none()};
-        raae::stat_jobs<3>(jobs, false);
+        raae::stat_jobs_wide<3>(jobs, false);
     } else {
         if (g_bn) {
             raae::bn_prologue(a.out_bn, a.N, o_mean, o_rstd, false);
@@ -249,7 +393,7 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
     if (a.g_kind == RAAE_G_PRELU_BN || a.g_kind == RAAE_G_PRELU)
         for (int n = tid; n < a.N; n += 256) o_slope[n] = a.out_slope[n];
     if (a.in_kind != RAAE_IN_NONE)
-        for (int k = tid; k < a.K; k += 256) i_slope[k] = a.slope[k];
+        for (int k = tid; k < Kl; k += 256) i_slope[k] = a.slope[k0 + k];
     __syncthreads();
 
     f32x4 wacc[TPW];
@@ -258,34 +402,44 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
     double dxs[KT4], dxq[KT4];
 #pragma unroll
     for (int i = 0; i < KT4; ++i) { dxs[i] = 0.0; dxq[i] = 0.0; }
-    // G staging: thread owns column(s) n = tid (+256) when N > 64, else n = tid % 64 with row phase tid/64
-    const bool wideN = a.N > 64;
-    const int gcol0 = wideN ? tid : (tid & 63);
-    const int grow0 = wideN ? 0 : (tid >> 6);
-    const int grstep = wideN ? 1 : 4;
-    double db_acc[2] = {0.0, 0.0}, ds_acc[2] = {0.0, 0.0};
+    double db_acc[H], ds_acc[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) { db_acc[h] = 0.0; ds_acc[h] = 0.0; }
 
-    const bool zb = (st & RAAE_ST_Z) != 0;
-    const int ntiles = (a.B + 15) >> 4;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile << 4;
+        const bool more = tile + (int)gridDim.x < ntiles;
+        if (!GPRE) g_load(row0);
+        if (!XPRE && vec) {            // widest shapes: two float4s at a time, staged at once
+#pragma unroll 1
+            for (int c0 = 0; c0 < NV; c0 += 2) {
+                RawTile<2> part;
+                int r2[2], c2[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int f = tid + 256 * (c0 + u), kq = Kl >> 2;
+                    r2[u] = f / kq; c2[u] = (f - r2[u] * kq) << 2;
+                }
+                tile_load<2>(part, r2, c2, a.x, xb, ms, row0, a.B, a.K, k0);
+                tile_store<2>(part, r2, c2, Xs, need_y ? Ys : nullptr, need_m ? Ms : nullptr, a.pitch_x, a.in_kind, i_slope,
+                              i_mean, i_rstd);
+            }
+        }
         // ---- 1. dL/dz tile -> Gs (zero padded) ----
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < H; ++h) {
             const int n = gcol0 + h * 256;
-            if (h == 1 && !(wideN && n < N16)) break;
             if (n >= N16) continue;
-            for (int r = grow0; r < 16; r += grstep) {
-                const int row = row0 + r;
+#pragma unroll
+            for (int j = 0; j < GR; ++j) {
+                const int r = grow0 + j * grstep, row = row0 + r;
                 float dz = 0.f;
                 if (row < a.B && n < a.N) {
-                    const size_t o = (size_t)row * a.N + n;
-                    const float gv = a.g[o];
+                    const float gv = gq[h][j], zv = zq[h][j];
                     if (a.g_kind == RAAE_G_DIRECT) dz = gv;
-                    else if (a.g_kind == RAAE_G_SOFTPLUS) dz = gv * (1.f - expf(-2.f * a.zout[o]));
-                    else if (a.g_kind == RAAE_G_RELU) dz = a.zout[o] > 0.f ? gv : 0.f;
+                    else if (a.g_kind == RAAE_G_SOFTPLUS) dz = gv * (1.f - expf(-2.f * zv));
+                    else if (a.g_kind == RAAE_G_RELU) dz = zv > 0.f ? gv : 0.f;
                     else {
-                        const float zv = zb ? bf16_at(a.zout, o) : a.zout[o];
                         float da = gv;
                         if (a.g_kind == RAAE_G_PRELU_BN) {
                             const float y = (prelu(zv, o_slope[n]) - o_mean[n]) * o_rstd[n];
@@ -299,8 +453,21 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
                 Gs[r * a.pitch_g + n] = dz;
             }
         }
-        // ---- 2. layer input tile -> Xs (transform applied) ----
-        stage_rows(Xs, a.pitch_x, a.x, a.mask, row0, a.B, a.K, K16, a.in_kind, i_slope, i_mean, i_rstd, st);
+        // ---- 2. layer input tile -> Xs (transform applied; Ys / Ms for the dx epilogue) ----
+        if (vec && XPRE) tile_store<NV>(raw, rr, cc, Xs, need_y ? Ys : nullptr, need_m ? Ms : nullptr, a.pitch_x, a.in_kind,
+                                        i_slope, i_mean, i_rstd);
+        else if (!vec) stage_rows_scalar(Xs, need_y ? Ys : nullptr, need_m ? Ms : nullptr, a.pitch_x, a.x, xb, ms, row0, a.B, a.K, K16,
+                                         a.in_kind, i_slope, i_mean, i_rstd);       // (never split: kw == K)
+        if (vec && K16 != Kl) {        // zero the padding columns K .. K16 (K % 16 != 0, K % 4 == 0)
+            for (int idx = tid; idx < 16 * (K16 - Kl); idx += 256) {
+                const int r = idx / (K16 - Kl), k = Kl + idx - r * (K16 - Kl);
+                Xs[r * a.pitch_x + k] = 0.f;
+            }
+        }
+        if (more) {                    // the next tile's operands fly during this tile's matrix work
+            if (GPRE) g_load((tile + gridDim.x) << 4);
+            if (XPRE && vec) tile_load<NV>(raw, rr, cc, a.x, xb, ms, (tile + gridDim.x) << 4, a.B, a.K, k0);
+        }
         __syncthreads();
         // ---- 3. dW[n][k] += sum_rows dz[row][n] * xin[row][k]; wave owns tiles t = wv + 4 i ----
 #pragma unroll
@@ -309,10 +476,10 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
             if (t < NT * KT) {
                 const int tn = t / KT, tk = t - tn * KT;
                 const float* ga = Gs + (lane >> 4) * a.pitch_g + tn * 16 + (lane & 15);
-                const float* xb = Xs + (lane >> 4) * a.pitch_x + tk * 16 + (lane & 15);
+                const float* xbp = Xs + (lane >> 4) * a.pitch_x + tk * 16 + (lane & 15);
 #pragma unroll
                 for (int r4 = 0; r4 < 16; r4 += 4)
-                    wacc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[r4 * a.pitch_g], xb[r4 * a.pitch_x], wacc[i], 0, 0, 0);
+                    wacc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[r4 * a.pitch_g], xbp[r4 * a.pitch_x], wacc[i], 0, 0, 0);
             }
         }
         // ---- 4. dx[row][k] = (sum_n dz[row][n] W[n][k]) * mask ; partial sums for the input's BN ----
@@ -324,44 +491,49 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                     const int kcol = tk * 16 + (lane & 15);
                     const float* ga = Gs + (lane & 15) * a.pitch_g + (lane >> 4);
-                    const bool kok = kcol < a.K;
-                    // B operand W[n][kcol]: 16 independent loads in flight per group of 16 MFMA steps
-                    const float* wp = a.w + (size_t)(lane >> 4) * a.K + kcol;
-                    int nn = 0;
-                    for (; nn + 64 <= N16; nn += 64) {
-                        float bb[16];
+                    const bool kok = kcol < Kl;
+                    if (WREGS) {
 #pragma unroll
-                        for (int u = 0; u < 16; ++u) {
-                            const int n = nn + 4 * u + (lane >> 4);
-                            bb[u] = (kok && n < a.N) ? wp[(size_t)(nn + 4 * u) * a.K] : 0.f;
+                        for (int u = 0; u < (WREGS ? NQ : 1); ++u)
+                            if (4 * u < N16) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[4 * u], wdx[WREGS ? i : 0][u], acc, 0, 0, 0);
+                    } else {
+                        // B operand W[n][kcol] from memory: 16 independent loads in flight per group of 16 MFMA steps
+                        const float* wp = a.w + (size_t)(lane >> 4) * a.K + k0 + kcol;
+                        int nn = 0;
+                        for (; nn + 64 <= N16; nn += 64) {
+                            float bb[16];
+#pragma unroll
+                            for (int u = 0; u < 16; ++u) {
+                                const int n = nn + 4 * u + (lane >> 4);
+                                bb[u] = (kok && n < a.N) ? wp[(size_t)(nn + 4 * u) * a.K] : 0.f;
+                            }
+#pragma unroll
+                            for (int u = 0; u < 16; ++u)
+                                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[nn + 4 * u], bb[u], acc, 0, 0, 0);
                         }
+                        for (; nn < N16; nn += 16) {
+                            float bb[4];
 #pragma unroll
-                        for (int u = 0; u < 16; ++u)
-                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[nn + 4 * u], bb[u], acc, 0, 0, 0);
-                    }
-                    for (; nn < N16; nn += 16) {
-                        float bb[4];
+                            for (int u = 0; u < 4; ++u) {
+                                const int n = nn + 4 * u + (lane >> 4);
+                                bb[u] = (kok && n < a.N) ? wp[(size_t)(nn + 4 * u) * a.K] : 0.f;
+                            }
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int n = nn + 4 * u + (lane >> 4);
-                            bb[u] = (kok && n < a.N) ? wp[(size_t)(nn + 4 * u) * a.K] : 0.f;
+                            for (int u = 0; u < 4; ++u)
+                                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[nn + 4 * u], bb[u], acc, 0, 0, 0);
                         }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[nn + 4 * u], bb[u], acc, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);     // keep the next column tile's 16 loads out of this one's registers
                     }
                     if (kok) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const int row = row0 + (lane >> 4) * 4 + j;
+                            const int r = (lane >> 4) * 4 + j, row = row0 + r;
                             if (row < a.B) {
-                                const size_t o = (size_t)row * a.K + kcol;
                                 float d = acc[j];
-                                if (a.in_kind != RAAE_IN_NONE && a.mask) d *= (st & RAAE_ST_MASK) ? bf16_at(a.mask, o) : a.mask[o];
-                                a.dx[o] = d;
-                                if (a.dx_partials != nullptr) {
-                                    const float xv = (st & RAAE_ST_X) ? bf16_at(a.x, o) : a.x[o];
-                                    const float y = (prelu(xv, i_slope[kcol]) - i_mean[kcol]) * i_rstd[kcol];
+                                if (need_m) d *= Ms[r * a.pitch_x + kcol];
+                                a.dx[(size_t)row * a.K + k0 + kcol] = d;
+                                if (need_y) {
+                                    const float y = Ys[r * a.pitch_x + kcol];
                                     dxs[i] += (double)d;
                                     dxq[i] += (double)d * (double)y;
                                 }
@@ -385,14 +557,15 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n = tn * 16 + (lane >> 4) * 4 + j;
-                if (n < a.N && k < a.K) a.dw[slab + (size_t)n * a.K + k] = wacc[i][j];
+                if (n < a.N && k < Kl) a.dw[slab + (size_t)n * a.K + k0 + k] = wacc[i][j];
             }
         }
     }
-    // db / dslope: combine the row-phase copies of each column in fixed order
-    if (wideN) {
+    // db / dslope: combine the row-phase copies of each column in fixed order (the first column slice writes them)
+    if (blockIdx.y != 0) {
+    } else if (WIDE) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < H; ++h) {
             const int n = tid + h * 256;
             if (n < a.N) {
                 a.db[slab + n] = (float)db_acc[h];
@@ -417,17 +590,25 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
             s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);
             s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
             const int kcol = tk * 16 + (lane & 15);
-            if (tk < KT && lane < 16 && kcol < a.K) {
-                double* p = a.dx_partials + ((size_t)blockIdx.x * a.K + kcol) * 2;
+            if (tk < KT && lane < 16 && kcol < Kl) {
+                double* p = a.dx_partials + ((size_t)blockIdx.x * a.K + k0 + kcol) * 2;
                 p[0] = s; p[1] = q;
             }
         }
     }
 }
 
+// Workgroups (= partial-statistic rows / gradient slabs) of a dense launch over B rows.  Every consumer reduces all
+// partial rows in its prologue, in every workgroup: rows x workgroups grows with the square of the grid, so large
+// batches use FEWER, longer-running workgroups -- 16-row tiles one after the other, the next tile's loads in flight
+// during the current tile's matrix work (256 workgroups of one tile each at 4096 rows meant 256 KB of partials per
+// workgroup: 15 of the 20 us of a 64-wide layer).
 int pick_grid(int B) {
     const int ntiles = (B + 15) / 16;
-    return ntiles < 256 ? ntiles : 256;
+    int cap = ntiles / 8;
+    if (cap > RAAE_MAX_PARTS) cap = RAAE_MAX_PARTS;
+    if (cap < 64) cap = 64;
+    return ntiles < cap ? ntiles : cap;
 }
 
 }  // namespace
@@ -447,6 +628,8 @@ static int prep_dense_fwd(const float* x, int B, int K, int in_kind, const float
     a.w = w; a.bias = bias; a.N = N; a.z = z; a.out_kind = out_kind; a.out_slope = out_slope;
     a.out_partials = out_partials;
     a.storage = 0;
+    a.mask_scale = 1.f;
+    a.gen.state = nullptr; a.gen.offset = 0; a.gen.keep = 1.f;
     const int K4 = (K + 3) & ~3;
     RAAE_CHECK_ARG(K4 <= 512 && (in_kind != RAAE_IN_PRELU_BN_DROP || K <= 256));
     a.pitch = K4 + 2;
@@ -496,7 +679,8 @@ extern "C" int raae_dense_fwd_s(const raae_dense_fwd_t* p, int* out_nparts, void
     const int rc = prep_dense_fwd(p->x, p->B, p->K, p->in_kind, p->slope, p->has_bn ? &p->bn : nullptr, p->mask, p->w,
                                   p->bias, p->N, p->z, p->out_kind, p->out_slope, p->out_partials, a, grid, lds, kq);
     if (rc) return rc;
-    a.storage = p->storage;
+    RAAE_CHECK_ARG(!(p->gen.state && p->mask) && !(p->gen.state && !(p->gen.keep > 0.f)));
+    a.storage = p->storage; a.mask_scale = p->mask_scale; a.gen = p->gen;
     if (out_nparts) *out_nparts = (int)grid.x;
     launch_dense_fwd(a, grid, lds, kq, (hipStream_t)stream);
     RAAE_LAUNCH_RET();
@@ -515,7 +699,10 @@ extern "C" int raae_dense_fwd2(const raae_dense_fwd_t* p, const raae_dense_fwd_t
     rc = prep_dense_fwd(q->x, q->B, q->K, q->in_kind, q->slope, q->has_bn ? &q->bn : nullptr, q->mask, q->w, q->bias,
                         q->N, q->z, q->out_kind, q->out_slope, q->out_partials, k.y, g2, l2, q2);
     if (rc) return rc;
+    RAAE_CHECK_ARG(!(p->gen.state && p->mask) && !(q->gen.state && q->mask));
     k.x.storage = p->storage; k.y.storage = q->storage;
+    k.x.mask_scale = p->mask_scale; k.y.mask_scale = q->mask_scale;
+    k.x.gen = p->gen; k.y.gen = q->gen;
     if (nparts_p) *nparts_p = (int)g1.x;
     if (nparts_q) *nparts_q = (int)g2.x;
     hipStream_t st = (hipStream_t)stream;
@@ -549,48 +736,83 @@ extern "C" int raae_dense_bwd_st(const float* g, int g_kind, const double* g_par
                                  const float* mask, const float* w,
                                  float* dw, float* db, float* dslope, long slab_stride, int* nslab,
                                  float* dx, double* dx_partials, int storage, void* stream) {
+    raae_dense_bwd_t p = {};
+    p.g = g; p.g_kind = g_kind; p.g_partials = g_partials; p.g_nparts = g_nparts; p.zout = zout; p.out_slope = out_slope;
+    p.has_out_bn = out_bn ? 1 : 0;
+    if (out_bn) p.out_bn = *out_bn;
+    p.B = B; p.N = N; p.x = x; p.K = K; p.in_kind = in_kind; p.slope = slope;
+    p.has_bn = bn ? 1 : 0;
+    if (bn) p.bn = *bn;
+    p.mask = mask; p.w = w; p.dw = dw; p.db = db; p.dslope = dslope; p.slab_stride = slab_stride; p.dx = dx;
+    p.dx_partials = dx_partials; p.storage = storage; p.mask_scale = 1.f;
+    return raae_dense_bwd_s(&p, nslab, stream);
+}
+
+extern "C" int raae_dense_bwd_s(const raae_dense_bwd_t* p, int* nslab, void* stream) {
+    RAAE_CHECK_ARG(p);
+    const int storage = p->storage, B = p->B, N = p->N, K = p->K, g_kind = p->g_kind, in_kind = p->in_kind;
+    const raae_bn_t* out_bn = p->has_out_bn ? &p->out_bn : nullptr;
+    const raae_bn_t* bn = p->has_bn ? &p->bn : nullptr;
     RAAE_CHECK_ARG((storage & ~(RAAE_ST_X | RAAE_ST_MASK | RAAE_ST_Z)) == 0 && (!(storage & RAAE_ST_X) || (K & 3) == 0));
-    RAAE_CHECK_ARG(g && x && w && dw && db && B > 0 && N > 0 && K > 0 && N <= 512 && K <= 512);
+    RAAE_CHECK_ARG(p->g && p->x && p->w && p->dw && p->db && B > 0 && N > 0 && K > 0 && N <= 512 && K <= 512);
     RAAE_CHECK_ARG(g_kind >= 0 && g_kind <= 4 && in_kind >= 0 && in_kind <= 2);
-    RAAE_CHECK_ARG(g_kind == RAAE_G_DIRECT || zout);
-    RAAE_CHECK_ARG(!(g_kind == RAAE_G_PRELU_BN) || (g_partials && out_bn && out_slope && g_nparts > 0 && g_nparts <= RAAE_MAX_PARTS));
-    RAAE_CHECK_ARG(!(g_kind == RAAE_G_PRELU) || out_slope);
-    RAAE_CHECK_ARG(in_kind == RAAE_IN_NONE || slope);
+    RAAE_CHECK_ARG(g_kind == RAAE_G_DIRECT || p->zout);
+    RAAE_CHECK_ARG(!(g_kind == RAAE_G_PRELU_BN) || (p->g_partials && out_bn && p->out_slope && p->g_nparts > 0 && p->g_nparts <= RAAE_MAX_PARTS));
+    RAAE_CHECK_ARG(!(g_kind == RAAE_G_PRELU) || p->out_slope);
+    RAAE_CHECK_ARG(in_kind == RAAE_IN_NONE || p->slope);
     RAAE_CHECK_ARG(in_kind != RAAE_IN_PRELU_BN_DROP || bn);
-    RAAE_CHECK_ARG(!(dx && in_kind == RAAE_IN_PRELU_BN_DROP) || dx_partials);
+    RAAE_CHECK_ARG(!(p->dx && in_kind == RAAE_IN_PRELU_BN_DROP) || p->dx_partials);
+    RAAE_CHECK_ARG(!(p->gen.state && p->mask) && !(p->gen.state && !(p->gen.keep > 0.f)));
     DenseBwdArgs a;
-    a.g = g; a.g_kind = g_kind; a.g_partials = g_partials; a.g_nparts = g_nparts; a.zout = zout;
-    a.out_slope = out_slope;
+    a.g = p->g; a.g_kind = g_kind; a.g_partials = p->g_partials; a.g_nparts = p->g_nparts; a.zout = p->zout;
+    a.out_slope = p->out_slope;
     raae_bn_t z0 = {};
     a.out_bn = out_bn ? *out_bn : z0;
-    a.B = B; a.N = N; a.x = x; a.K = K; a.in_kind = in_kind; a.slope = slope;
+    a.B = B; a.N = N; a.x = p->x; a.K = K; a.in_kind = in_kind; a.slope = p->slope;
     a.bn = bn ? *bn : z0;
     RAAE_CHECK_ARG(a.bn.nparts <= RAAE_MAX_PARTS && a.out_bn.nparts <= RAAE_MAX_PARTS);
-    a.mask = mask; a.w = w; a.dw = dw; a.db = db; a.dslope = dslope; a.slab_stride = slab_stride;
-    a.dx = dx; a.dx_partials = (in_kind == RAAE_IN_PRELU_BN_DROP) ? dx_partials : nullptr;
-    const int N16 = (N + 15) & ~15, K16 = (K + 15) & ~15;
+    a.mask = p->mask; a.w = p->w; a.dw = p->dw; a.db = p->db; a.dslope = p->dslope; a.slab_stride = p->slab_stride;
+    a.dx = p->dx; a.dx_partials = (in_kind == RAAE_IN_PRELU_BN_DROP) ? p->dx_partials : nullptr;
+    // first layers (no input transform, hence no statistics over K) with 256 / 512 input points: slices of 128 columns
+    const bool split = in_kind == RAAE_IN_NONE && N <= 64 && K >= 256 && (K % 128) == 0;
+    a.kw = split ? 128 : K;
+    const int N16 = (N + 15) & ~15, K16 = (a.kw + 15) & ~15;
     a.pitch_g = N16 + 2; a.pitch_x = K16 + 2;
-    a.storage = storage;
+    a.storage = storage; a.mask_scale = p->mask_scale; a.gen = p->gen;
     const int tiles = (N16 / 16) * (K16 / 16);
     const int tpw = (tiles + 3) / 4, kt4 = (K16 / 16 + 3) / 4;
-    const size_t lds = sizeof(float) * (5 * (size_t)N16 + 3 * (size_t)K16 + 16 * (size_t)(a.pitch_g + a.pitch_x) + 512);
+    const size_t lds = sizeof(float) * (5 * (size_t)N16 + 3 * (size_t)K16 + 16 * (size_t)a.pitch_g + 48 * (size_t)a.pitch_x + 512);
     RAAE_CHECK_ARG(lds <= 160 * 1024);
     // cap the number of slabs: each slab is N*K floats that the Adam kernel re-reads
     int gx = pick_grid(B);
     if ((long)N * K >= 8192 && gx > 64) gx = 64;
     if (nslab) *nslab = gx;
-    dim3 grid(gx), block(256);
+    dim3 grid(gx, K / a.kw), block(256);
     hipStream_t st = (hipStream_t)stream;
-    const bool need_dx = dx != nullptr;
-#define RAAE_BWD(TPW_, KT4_) do { if (storage) hipLaunchKernelGGL((dense_bwd_kernel<TPW_, KT4_, true>), grid, block, lds, st, a); \
-                                 else hipLaunchKernelGGL((dense_bwd_kernel<TPW_, KT4_, false>), grid, block, lds, st, a); } while (0)
-    if (tpw <= 1 && kt4 <= 1) RAAE_BWD(1, 1);
-    else if (tpw <= 4 && kt4 <= 1) RAAE_BWD(4, 1);
-    else if (tpw <= 16 && (kt4 <= 1 || !need_dx)) RAAE_BWD(16, 1);
-    else if (tpw <= 16 && kt4 <= 4) RAAE_BWD(16, 4);
-    else if (tpw <= 32 && (kt4 <= 1 || !need_dx)) RAAE_BWD(32, 1);
-    else if (tpw <= 32 && kt4 <= 8) RAAE_BWD(32, 8);
-    else return RAAE_EINVAL;
+    const bool need_dx = p->dx != nullptr;
+    const int nq = N <= 64 ? 16 : (N <= 256 ? 64 : 0);
+#define RAAE_BWD(TPW_, KT4_, NQ_) do { if (storage) hipLaunchKernelGGL((dense_bwd_kernel<TPW_, KT4_, NQ_, true>), grid, block, lds, st, a); \
+                                      else hipLaunchKernelGGL((dense_bwd_kernel<TPW_, KT4_, NQ_, false>), grid, block, lds, st, a); } while (0)
+    // (KT4 also sizes the per-thread input tile: K16 / 64 float4s, so it follows K even when dx is not needed)
+    if (nq == 16) {
+        if (tpw <= 1 && kt4 <= 1) RAAE_BWD(1, 1, 16);
+        else if (tpw <= 4 && kt4 <= 1) RAAE_BWD(4, 1, 16);
+        else if (tpw <= 8 && kt4 <= 2) RAAE_BWD(8, 2, 16);           // a 128-column slice of a first layer
+        else if (tpw <= 16 && kt4 <= 4) RAAE_BWD(16, 4, 16);
+        else if (tpw <= 32 && kt4 <= 8) RAAE_BWD(32, 8, 16);
+        else return RAAE_EINVAL;
+    } else if (nq == 64) {
+        if (tpw <= 4 && kt4 <= 1) RAAE_BWD(4, 1, 64);
+        else if (tpw <= 16 && kt4 <= 1) RAAE_BWD(16, 1, 64);
+        else if (tpw <= 32 && kt4 <= 1) RAAE_BWD(32, 1, 64);
+        else if (tpw <= 32 && kt4 <= 8) RAAE_BWD(32, 8, 0);      // W operands from memory
+        else return RAAE_EINVAL;
+    } else {
+        if (tpw <= 32 && kt4 <= 1) RAAE_BWD(32, 1, 0);
+        else if (tpw <= 32 && kt4 <= 8) RAAE_BWD(32, 8, 0);
+        else return RAAE_EINVAL;
+    }
+    (void)need_dx;
 #undef RAAE_BWD
     RAAE_LAUNCH_RET();
 }

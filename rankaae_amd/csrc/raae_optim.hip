@@ -152,30 +152,34 @@ __global__ __launch_bounds__(256) void rng_fill_kernel(float* tape, const int* s
         }
         const int kind = seg_desc[lo * 4 + 2];
         const long send = (long)seg_desc[lo * 4] + seg_desc[lo * 4 + 1];
-        uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)ctr, (uint32_t)(ctr >> 32)};
-        philox(c, (uint32_t)seed, (uint32_t)(seed >> 32));
         float o[4];
-        if (kind == 2) {
-            // dropout multipliers stored as bf16 (`precision: bf16`): this thread's four floats hold eight of them;
-            // a second Philox block (counter word 1 with its top bit set) supplies draws five to eight
-            uint32_t c2[4] = {(uint32_t)q, (uint32_t)(q >> 32) | 0x80000000u, (uint32_t)ctr, (uint32_t)(ctr >> 32)};
-            philox(c2, (uint32_t)seed, (uint32_t)(seed >> 32));
-            const float keep = seg_scale[lo];
-            const uint32_t one = (uint32_t)(__float_as_uint(1.f / keep) + 0x7fffu + ((__float_as_uint(1.f / keep) >> 16) & 1u)) >> 16;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t lo16 = u01(c[j]) < keep ? one : 0u, hi16 = u01(c2[j]) < keep ? one : 0u;
-                o[j] = __uint_as_float(lo16 | (hi16 << 16));       // elements 2 (e0 + j), 2 (e0 + j) + 1 of the bf16 view
-            }
-        } else
         if (kind == 0) {
+            // Philox counter = (position of these four floats in the numbering of the step's Gaussian elements) / 4
+            const long qg = ((long)seg_desc[lo * 4 + 3] + (e0 - seg_desc[lo * 4])) >> 2;
+            uint32_t c[4] = {(uint32_t)qg, (uint32_t)(qg >> 32), (uint32_t)ctr, (uint32_t)(ctr >> 32)};
+            philox(c, (uint32_t)seed, (uint32_t)(seed >> 32));
             const float r0 = sqrtf(-2.f * logf(u01(c[0]))), r1 = sqrtf(-2.f * logf(u01(c[2])));
             const float a0 = 6.283185307179586f * u01(c[1]), a1 = 6.283185307179586f * u01(c[3]);
             o[0] = r0 * cosf(a0); o[1] = r0 * sinf(a0); o[2] = r1 * cosf(a1); o[3] = r1 * sinf(a1);
-        } else {
-            const float keep = seg_scale[lo], inv = 1.f / keep;
+        } else if (kind == 1) {
+            // dropout multipliers {0, 1/keep}: the counter-based hash of raae_common.h on the element's tape index --
+            // the function a kernel with a raae_maskgen_t evaluates for a slot it generates itself
+            // (hash index = the slot's position in the numbering of ALL dropout elements of the step, seg_desc[.][3],
+            // + the element's index in the slot: the same whether the slot lives on the tape or in its consumer)
+            const raae::MaskGen g = raae::mask_gen_make(seed, ctr, (uint32_t)seg_desc[lo * 4 + 3], seg_scale[lo]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = u01(c[j]) < keep ? inv : 0.f;
+            for (int j = 0; j < 4; ++j) o[j] = raae::mask_val(g, (uint32_t)(e0 + j - seg_desc[lo * 4]));
+        } else {
+            // kind 2 (`precision: bf16`): keep flags {0, 1} stored as bf16 -- this thread's four floats hold eight of
+            // them (bf16 element i of the slot is hashed at index i of the slot); the dense kernels multiply by the fp32
+            // 1/keep
+            const raae::MaskGen g = raae::mask_gen_make(seed, ctr, (uint32_t)seg_desc[lo * 4 + 3], seg_scale[lo]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t e = 2u * (uint32_t)(e0 + j - seg_desc[lo * 4]);
+                const uint32_t lo16 = raae::mask_keep(g, e) ? 0x3F80u : 0u, hi16 = raae::mask_keep(g, e + 1u) ? 0x3F80u : 0u;
+                o[j] = __uint_as_float(lo16 | (hi16 << 16));
+            }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (e0 + j < send && e0 + j < total) tape[e0 + j] = o[j];

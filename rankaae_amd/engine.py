@@ -93,17 +93,35 @@ class Tape:
 
     def __init__(self):
         self.total = 0
-        self.segs = []      # (offset, count, kind, keep)   kind 0 = N(0,1), 1 = dropout scale
+        self.htotal = 0     # dropout elements numbered so far (resident and virtual slots alike)
+        self.gtotal = 0     # Gaussian elements numbered so far
+        self.hash_off = {}
+        self.segs = []      # (offset, count, kind, keep, hash offset)   kind 0 = N(0,1), 1 = dropout scale
         self.draws = []     # in reference order: ("normal"|"mask", offset, shape, keep) | ("int64",)
         self.buf = None
 
-    def slot(self, count, kind, keep=1.0):
-        """``kind`` 0: N(0,1) floats; 1: dropout multipliers (0 or 1/keep) as floats; 2: the same stored as bf16
-        (``precision: bf16``) -- ``count`` values in ``(count + 1) // 2`` floats of the buffer."""
+    def slot(self, count, kind, keep=1.0, virtual=False):
+        """``kind`` 0: N(0,1) floats; 1: dropout multipliers (0 or 1/keep) as floats; 2: dropout keep flags {0, 1} stored
+        as bf16 (``precision: bf16``; the consumer multiplies by the fp32 1/keep) -- ``count`` values in
+        ``(count + 1) // 2`` floats of the buffer.  Returns the slot's tape offset; ``self.hash_off[offset]`` is the
+        slot's position in the numbering of all dropout elements of a step (what the hash that decides an element is
+        keyed with).  ``virtual``: a kind-1 slot whose multipliers the consumer generates itself (``raae_maskgen_t``):
+        no tape memory, nothing to fill; returns ``-(hash offset) - 1``."""
+        if kind == 0:       # Gaussian slots are numbered apart (their Philox counter = numbering / 4), so that the noise
+            hoff = self.gtotal          # does not depend on which dropout slots live on the tape
+            self.gtotal += (count + 3) // 4 * 4
+        else:
+            hoff = self.htotal
+            self.htotal += (count + 3) // 4 * 4
+            assert self.htotal < (1 << 31)
+        if virtual:
+            assert kind == 1
+            return -hoff - 1
         off = self.total
         nfloat = (count + 1) // 2 if kind == 2 else count
-        self.segs.append((off, nfloat, kind, keep))
+        self.segs.append((off, nfloat, kind, keep, hoff))
         self.total += (nfloat + 3) // 4 * 4
+        self.hash_off[off] = hoff
         return off
 
     def draw(self, kind, off, shape, keep=1.0):
@@ -111,9 +129,9 @@ class Tape:
 
     def finalize(self, device):
         self.buf = torch.zeros(max(self.total, 4), device=device)
-        d = torch.tensor([[o, c, k, 0] for o, c, k, _ in self.segs], dtype=torch.int32)
+        d = torch.tensor([[o, c, k, h] for o, c, k, _, h in self.segs], dtype=torch.int32)
         self.seg_desc = d.to(device)
-        self.seg_scale = torch.tensor([kp for *_, kp in self.segs], dtype=torch.float32).to(device)
+        self.seg_scale = torch.tensor([kp for _, _, _, kp, _ in self.segs], dtype=torch.float32).to(device)
         self.host = torch.zeros(max(self.total, 4)).pin_memory() if torch.cuda.is_available() else None
 
     def view(self, off, *shape):
@@ -134,8 +152,8 @@ class Tape:
                 self.host[off:off + n] = torch.randn(*shape).reshape(-1)
             elif kind == "mask":
                 self.host[off:off + n] = torch.empty(*shape).bernoulli_(keep).div_(keep).reshape(-1)
-            elif kind == "mask16":      # the same draw, stored as bf16
-                m16 = torch.empty(*shape).bernoulli_(keep).div_(keep).reshape(-1).to(torch.bfloat16)
+            elif kind == "mask16":      # the same draw, stored as bf16 keep flags {0, 1} (the kernels multiply by 1/keep)
+                m16 = torch.empty(*shape).bernoulli_(keep).reshape(-1).to(torch.bfloat16)
                 self.host[off:off + (n + 1) // 2].view(torch.bfloat16)[:n] = m16
             else:
                 raise ValueError(kind)
@@ -206,18 +224,25 @@ class FCNet:
     def mask_slots(self, tape, b, train=True):
         """Allocate + record (in forward order) the dropout masks of one forward pass."""
         masks = []
+        inline = self.eng.inline_masks and not self.bf16
         for l in self.layers[:-1]:
             if train and l.p > 0:
-                off = tape.slot(b * l.N, 2 if self.bf16 else 1, 1.0 - l.p)
-                tape.draw("mask16" if self.bf16 else "mask", off, (b, l.N), 1.0 - l.p)
-                masks.append((off, (b, l.N)))
+                off = tape.slot(b * l.N, 2 if self.bf16 else 1, 1.0 - l.p, virtual=inline)
+                if not inline:
+                    tape.draw("mask16" if self.bf16 else "mask", off, (b, l.N), 1.0 - l.p)
+                masks.append((off, (b, l.N), 1.0 - l.p, inline))
             else:
                 masks.append(None)
         return masks
 
     def _mask(self, masks, i):
-        off, shape = masks[i]
-        return self.eng.tape.view16(off, *shape) if self.bf16 else self.eng.tape.view(off, *shape)
+        """``dict(mask=, gen=, mask_scale=)`` of layer i's dropout multipliers: a tape view, or the in-kernel generator."""
+        off, shape, keep, inline = masks[i]
+        if inline:
+            return dict(mask=None, gen=(self.eng.rng_state, -off - 1, keep), mask_scale=1.0)
+        if self.bf16:
+            return dict(mask=self.eng.tape.view16(off, *shape), gen=None, mask_scale=1.0 / keep)
+        return dict(mask=self.eng.tape.view(off, *shape), gen=None, mask_scale=1.0)
 
     def _bn_in(self, ws, i, train, update):
         p = self.layers[i]
@@ -271,7 +296,8 @@ class FCNet:
                 p = L[i - 1]
                 xin, in_kind, slope = ws.z[i - 1], IN_PRELU_BN_DROP, p.prelu.weight
                 bn = self._bn_in(ws, i - 1, train, True)
-                mask = self._mask(masks, i - 1) if (train and masks[i - 1]) else None
+                mk = self._mask(masks, i - 1) if (train and masks[i - 1]) else None
+                mask = mk["mask"] if mk else None
             if not last:
                 out_kind, oslope = OUT_STATS_PRELU, l.prelu.weight
             elif self.kind == "enc":
@@ -281,8 +307,9 @@ class FCNet:
             st = 0
             if self.bf16:
                 st = (_lib.ST_X if i > 1 else 0) | (_lib.ST_MASK if mask is not None else 0) | (_lib.ST_Z if 0 < i and not last else 0)
+            extra = dict(gen=mk["gen"], mask_scale=mk["mask_scale"]) if (i > 0 and mk) else {}
             ws.nparts[i] = yield ("dense", ops.dense_fwd_args(xin, b, l.K, in_kind, slope, bn, mask, l.w, l.b, l.N,
-                                                               ws.z[i], out_kind, oslope, ws.part[i], storage=st), 0)
+                                                               ws.z[i], out_kind, oslope, ws.part[i], storage=st, **extra), 0)
         if self.kind == "enc":
             ops.style_bn_fwd(ws.z[-1], b, self.out_dim, self._bn_in(ws, len(L) - 1, train, True), ws.styles)
         if train:
@@ -310,14 +337,16 @@ class FCNet:
                 p = L[i - 1]
                 xin, in_kind, slope = ws.z[i - 1], IN_PRELU_BN_DROP, p.prelu.weight
                 bn = self._bn_in(ws, i - 1, True, False)
-                mask = self._mask(masks, i - 1) if masks[i - 1] else None
+                mk = self._mask(masks, i - 1) if masks[i - 1] else None
+                mask = mk["mask"] if mk else None
                 dx, dxp = ws.dx[i & 1], ws.dxp[i & 1]
             ds = eng.gslab(l.prelu.weight) if gk == G_PRELU_BN else None
             st = 0
             if self.bf16:
                 st = (_lib.ST_X if i > 1 else 0) | (_lib.ST_MASK if mask is not None else 0) | (_lib.ST_Z if 0 < i < n - 1 else 0)
+            extra = dict(gen=mk["gen"], mask_scale=mk["mask_scale"]) if (i > 0 and mk) else {}
             ns = ops.dense_bwd(g, gk, gp, gnp, ws.z[i], oslope, out_bn, b, l.N, xin, l.K, in_kind, slope, bn, mask,
-                               l.w, eng.gslab(l.w), eng.gslab(l.b), ds, eng.arena.n, dx, dxp, storage=st)
+                               l.w, eng.gslab(l.w), eng.gslab(l.b), ds, eng.arena.n, dx, dxp, storage=st, **extra)
             eng.note_slabs([l.w, l.b] + ([l.prelu.weight] if ds is not None else []), ns)
             g, gk, gp, gnp = dx, G_PRELU_BN, dxp, ns
 
@@ -520,7 +549,13 @@ class StepEngine:
         self._make_optimizers()
         self.steps_dev = torch.zeros(8, dtype=torch.int32, device=device)
         self.cursor = torch.zeros(1, dtype=torch.int32, device=device)
-        self.rng_counter = torch.zeros(1, dtype=torch.int64, device=device)
+        # [0]: step counter (advanced by the step's tick), [1]: seed -- what the kernels that generate their own dropout
+        # multipliers read (raae_maskgen_t.state); rng_counter aliases [0] for raae_step_tick / raae_rng_fill
+        self.rng_state = torch.tensor([0, self.seed], dtype=torch.int64, device=device)
+        self.rng_counter = self.rng_state[0:1]
+        # build-only key `inline_masks` (rng_mode "philox" only; default on): dropout multipliers are regenerated by
+        # the kernels that apply them instead of written to and read from the random tape
+        self.inline_masks = self.rng_mode == "philox" and bool(cfg.get("inline_masks", True))
         self.alpha_dev = torch.zeros(1, device=device)
         self.loss_out = torch.zeros(8, device=device)
         self.taps = gaussian_taps(17, 3.0).tolist()
@@ -702,12 +737,26 @@ class StepEngine:
             off += t.numel()
 
     def close(self):
-        """Release the private RCCL communicator (data-parallel runs)."""
-        if self.graph_ar is not None:
-            self.graph_ar.close()
-            self.graph_ar = None
+        """Release the private RCCL communicator (data-parallel runs).  ``Trainer.train`` calls it when the run ends, so
+        that every rank destroys its communicator at the same point of the program.  Never while a hipGraph is being
+        captured (``ncclCommDestroy`` synchronises and frees, which is illegal during capture): then it is a no-op and
+        the communicator stays for a later call.  The captured steps hold nodes of that communicator: they are dropped,
+        and a later ``step`` emits and captures again over ``torch.distributed`` between graph segments."""
+        if self.graph_ar is None or self._capture is not None or ops.Graph.active > 0:
+            return
+        torch.cuda.synchronize(self.device)
+        for P in self.plans.values():
+            if hasattr(P, "graphs"):
+                P.graphs = {}
+            if getattr(P, "graph", None) is not None:
+                P.graph, P.seen = None, 0
+        self.graph_ar.close()
+        self.graph_ar = None
 
     def __del__(self):
+        # the cyclic collector runs this at an arbitrary allocation point, possibly inside ANOTHER engine's capture
+        # window in the same process (the next trial): close() refuses there, the communicator is then released with
+        # the process
         try:
             self.close()
         except Exception:      # noqa: BLE001 -- interpreter shutdown
@@ -1006,9 +1055,20 @@ class StepEngine:
         launches replayed from a small hipGraph between two HIP events on the launching stream.  Returns the ``top``
         kernel families by share of the summed kernel time, each with its algorithmic bytes per launch (ops.block_bytes
         and friends: SURVEY 8d's per-sample figure x the batch), average launch duration and fraction of the HBM peak;
-        the first one is the step's dominant kernel."""
+        the first one is the step's dominant kernel.
+
+        The replays are NOT idempotent (accumulating data-gradient kernels, ``out[acc_slot] += v`` loss finishers, Adam
+        steps on the results): the engine's trainable state -- parameters, Adam moments and step counts, BatchNorm
+        running statistics, loss slots, RNG counter -- is snapshotted before the probe and restored after it, so the
+        engine can go on training from where it was."""
         saved_graph = self.use_graph
         self.use_graph = False
+        torch.cuda.synchronize()
+        bufs = [self.arena.P, self.steps_dev, self.loss_out, self.rng_counter, self.cursor] + \
+               [t for o in self.opts.values() for t in (o.m, o.v)] + \
+               [b_ for mod in (self.enc_mod, self.dec_mod, self.dis_mod) for b_ in mod.buffers()]
+        snap = [t.clone() for t in bufs]
+        host = (dict(self.bn_counts), self._host_cursor, self._cursor_primed, self.cursor_start, self.cursor_stride)
         self.set_epoch(self.perm.clone(), float(self.alpha_dev))
         self.step(b, smooth=True)                  # plan + slab tables exist before the probe arms
         ops.PROBE = ops.Probe(PROBE_REPS, detail)
@@ -1020,6 +1080,10 @@ class StepEngine:
         finally:
             ops.PROBE = None
             self.use_graph = saved_graph
+            for t, v in zip(bufs, snap):
+                t.copy_(v)
+            self.bn_counts, self._host_cursor, self._cursor_primed, self.cursor_start, self.cursor_stride = host
+            torch.cuda.synchronize()
         total = sum(f["total_us"] for f in fams.values())
         rows = []
         for name, f in sorted(fams.items(), key=lambda kv: -kv[1]["total_us"]):
@@ -1128,6 +1192,12 @@ class StepEngine:
         c, dev, ns = self.cfg, self.device, self.nstyle
         nv, bc = val_spec.shape[0], c["batch_size"]
         key = ("val", nv)
+        # Data parallel: the O(n_val^2) rank loss is SHARDED -- every rank pairs its rows [row0, row0 + nrows) with all
+        # n_val rows (raae_rank_rows_pairs), the per-descriptor counts and sums meet in one 512-byte float64 all-reduce,
+        # and raae_rank_rows_finish forms the loss, identical on every rank and equal to the replicated computation to
+        # the order of the float64 sums (47 ms -> 47 / W ms at n_val = 150 k).  The O(n_val) parts (forwards, the four
+        # other losses, the style metrics, which need every row's styles) stay replicated.
+        shard = self.world_size > 1 and bool(c.get("shard_validation", True))
         if key not in self.plans:
             V = StepPlan()
             V.enc, V.dec = self.enc.alloc(nv), self.dec.alloc(nv)
@@ -1139,6 +1209,7 @@ class StepEngine:
             V.sl_disc = self.disc.tape_slots(V.tape, bc, nv, train=False)
             V.tape.finalize(dev)
             V.rank_work = torch.empty(ops.rank_loss_work_bytes(nv, self.n_aux), dtype=torch.uint8, device=dev)
+            V.rank_totals = torch.zeros(64, dtype=torch.float64, device=dev)
             V.lpart = torch.zeros(RAAE_MAX_PARTS, dtype=torch.float64, device=dev)
             V.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
             V.out = torch.zeros(8, device=dev)
@@ -1158,8 +1229,20 @@ class StepEngine:
             z = self.enc.forward(V.enc, val_spec, None, train=False)
             out = self.dec.forward(V.dec, z, None, train=False)
             ops.recon_loss_fwd_bwd(val_spec, out, nv, self.L, False, V.lpart, None, fin=(1.0, V.out, 2, -1, V.ticket))
-            ops.rank_loss_fwd_bwd(val_aux, self.n_aux, z, ns, nv, self.n_aux, c["kendall_activation"], V.rank_work,
-                                  V.out[1:2], None)
+            if shard:
+                per = (nv + self.world_size - 1) // self.world_size
+                row0 = min(self.rank * per, nv)
+                nrows = min(per, nv - row0)
+                if nrows > 0:
+                    ops.rank_rows_pairs(val_aux, self.n_aux, z, ns, nv, row0, nrows, self.n_aux, V.rank_work, V.rank_totals)
+                else:                       # more ranks than validation rows: this rank adds nothing
+                    V.rank_totals.zero_()
+                self._collective(V.rank_totals, "sum")
+                ops.rank_rows_finish(V.rank_totals, nv, max(nrows, 1), self.n_aux, c["kendall_activation"], 1.0,
+                                     V.rank_work, V.out[1:2], None, ns)
+            else:
+                ops.rank_loss_fwd_bwd(val_aux, self.n_aux, z, ns, nv, self.n_aux, c["kendall_activation"], V.rank_work,
+                                      V.out[1:2], None)
             ops.smooth_loss_fwd_bwd(out, nv, self.L, self.taps, V.lpart, None, fin=(1.0, V.out, 4, -1, V.ticket))
             z_s = V.tape.view(V.z_sample, nv, ns)
             out2 = self.dec.forward(V.dec, z_s, None, train=False)
@@ -1172,6 +1255,8 @@ class StepEngine:
         # like the training step: eager once, captured on the second call, replayed afterwards (the inputs must
         # then be the same device tensors: the trainer validates on one resident split)
         same = getattr(V, "inputs", None) == (val_spec.data_ptr(), val_aux.data_ptr())
+        if shard and self.graph_ar is None:
+            same = False        # the all-reduce goes through torch.distributed, which cannot be captured: eager every time
         if self.use_graph and same and getattr(V, "graph", None) is not None:
             V.graph.launch()
             z = V.z

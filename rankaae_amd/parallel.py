@@ -75,3 +75,14 @@ def broadcast_tensor_from_rank0(t, device, group=None):
     buf = t.to(device) if dist.get_backend(group) == "nccl" else t.clone()
     dist.broadcast(buf, src=0, group=group)
     return buf.cpu()
+
+
+def any_rank(flag, device, group=None):
+    """True on every rank iff ``flag`` is true on at least one (one tiny MAX all-reduce; every rank must call it)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+    if dist.get_backend(group) == "nccl":
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return bool(int(t.cpu()[0]))

@@ -74,6 +74,10 @@ class Trainer:
         self.train_loader, self.val_loader = train_loader, val_loader
         self.verbose, self.work_dir, self.tb_logdir = verbose, work_dir, tb_logdir
         self.epoch_stop_smooth = 500
+        # build-only key `freeze_gc` (default off for library use; `train_sc` and bench.py turn it on): after the second
+        # epoch the long-lived objects of the run move to the cyclic collector's permanent generation for the rest of
+        # train(), and come back out in a `finally` (process-global state: an embedding application opts in)
+        self.freeze_gc = False
         self.__dict__.update(config_parameters.to_dict())
         if not self.gradient_reversal or self.use_cnn_discriminator:
             raise ValueError("only gradient_reversal: true with DiscriminatorFC is reachable in the reference "
@@ -139,7 +143,32 @@ class Trainer:
         return out
 
     def train(self, callback=None):
-        from .parallel import broadcast_from_rank0, broadcast_tensor_from_rank0, epoch_schedule
+        eng = self.engine
+        try:
+            return self._train_epochs(callback)
+        finally:
+            # a worker process runs several trials: the next one must be able to collect this one's objects -- also when
+            # the run ends in an exception (the SIGALRM "Training Overtime!", a caller's try/except around train())
+            if self._gc_frozen:
+                gc.unfreeze()
+                self._gc_frozen = False
+            # every rank reaches this point at the same place in the program: release the private RCCL communicator
+            # here, not from __del__ at whatever allocation the cyclic collector happens to run
+            eng.close()
+
+    def request_stop(self, reason="Training Overtime!"):
+        """Ask ``train()`` to end with ``Exception(reason)`` at the next epoch boundary -- on EVERY rank of a
+        data-parallel run (the flag is OR-reduced over the ranks beside the per-epoch metrics broadcast), so that no
+        rank is left waiting in a collective.  ``train_sc``'s per-trial SIGALRM calls this under data parallelism
+        (reference: the handler raises at once, sc/cmd/train_sc.py:21-22; with one process that is what still happens)."""
+        self._stop_reason = reason
+
+    _stop_reason = None
+
+    _gc_frozen = False
+
+    def _train_epochs(self, callback):
+        from .parallel import any_rank, broadcast_from_rank0, broadcast_tensor_from_rank0, epoch_schedule
         eng = self.engine
         lead = self.rank == 0
         best_combined_metric = 10.0
@@ -172,11 +201,12 @@ class Trainer:
                     eng.seek(off + self.rank * rows, global_rows)
                 prev_rows = rows
                 eng.step(rows, smooth=smooth)
-            if epoch == 1:
+            if epoch == 1 and self.freeze_gc and not self._gc_frozen:
                 # plans, captured graphs and modules are long-lived: out of the cyclic collector's way (a full
                 # collection in the middle of an epoch stalls the host for longer than the queue of launched steps lasts)
                 gc.collect()
                 gc.freeze()
+                self._gc_frozen = True
             tl = eng.losses()
             if not smooth:
                 tl["smooth"] = 0.0
@@ -200,6 +230,10 @@ class Trainer:
             metrics = [float(np.min(style_shapiro)), vl["recon"], avg_mutual_info, float(style_coupling),
                        vl["kendall"]]
             metrics = broadcast_from_rank0(metrics, self.device, self.pg)     # no-op on one GPU
+            if self.world > 1 and any_rank(self._stop_reason is not None, self.device, self.pg):
+                # a rank's timeout fired: all ranks leave here together (a rank raising on its own would leave the
+                # others waiting in the next step's all-reduce)
+                raise Exception(self._stop_reason or "Training Overtime!")
             combined_metric = -(np.array(self.metric_weights) * np.array(metrics)).sum()
             if combined_metric > best_combined_metric:
                 best_combined_metric = combined_metric
@@ -210,7 +244,6 @@ class Trainer:
                 sch.step(combined_metric)
             if callback is not None:
                 callback(epoch, metrics)
-        gc.unfreeze()        # a worker process runs several trials: the next one must be able to collect this one's objects
         if lead:
             torch.save(self._model_dict(), f"{self.work_dir}/final.pt")
             if best_chpt_file is not None:

@@ -292,3 +292,177 @@ def test_train_sc_under_torch_distributed_run(tmp_path):
         assert rows[0].startswith("Epoch,Train_D") and [ln.split(",")[0] for ln in rows[1:]] == ["0", "10"], rows
         model = torch.load(job / "final.pt", map_location="cpu", weights_only=False)
         assert set(model) == {"Encoder", "Decoder", "Style Discriminator"}
+
+
+def test_communicator_released_at_a_defined_point_not_by_the_collector():
+    """the private RCCL communicator used to be released only by ``StepEngine.__del__``, i.e. by the cyclic
+    collector at an arbitrary allocation -- possibly inside the NEXT trial's hipGraph capture, where ``ncclCommDestroy``
+    is illegal.  Now ``Trainer.train`` ends with ``engine.close()``; ``close()`` refuses while any capture is in
+    progress in the process, drops the captured steps that hold the communicator's nodes, and a second engine built
+    afterwards captures its own."""
+    import torch.distributed as dist
+    import test_engine_gpu as T
+    from rankaae_amd import ops
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29643")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    g, cfg, spec, aux = T.load_case("fc_small")
+    cfg = dict(cfg, in_graph_allreduce=True)
+    bs = cfg["batch_size"]
+
+    def run(n_steps):
+        from rankaae_amd import model as pm
+        from rankaae_amd.engine import StepEngine
+        torch.manual_seed(77)
+        cls = pm.AE_CLS_DICT[cfg["ae_form"]]
+        enc = cls["encoder"](nstyle=cfg["nstyle"], dropout_rate=cfg["dropout_rate"], dim_in=cfg["dim_in"], n_layers=cfg["n_layers"])
+        dec = cls["decoder"](nstyle=cfg["nstyle"], dropout_rate=cfg["dropout_rate"], last_layer_activation=cfg["decoder_activation"],
+                             dim_out=cfg["dim_out"], n_layers=cfg["n_layers"])
+        dis = pm.DiscriminatorFC(nstyle=cfg["nstyle"], dropout_rate=cfg["dis_dropout_rate"], noise=cfg["dis_noise"],
+                                 layers=cfg["FC_discriminator_layers"])
+        eng = StepEngine(enc, dec, dis, cfg, T.DEV, rng_mode="philox", seed=9, use_graph=True, world_size=2, rank=0)
+        n_train = int(len(spec) * 0.7)
+        eng.set_data(spec[:n_train], aux[:n_train])
+        eng.set_epoch(torch.randperm(n_train, generator=torch.Generator().manual_seed(1)), 0.3)
+        for _ in range(n_steps):
+            eng.step(bs)
+        torch.cuda.synchronize()
+        return eng
+    try:
+        first = run(4)
+        assert first.graph_ar is not None, "the in-graph all-reduce failed its self-test on this box"
+        assert first.plans[bs].graphs[True] is not None
+        # inside a capture window (of any engine of the process) close() must do nothing
+        ops.Graph.active += 1
+        try:
+            first.close()
+            assert first.graph_ar is not None
+        finally:
+            ops.Graph.active -= 1
+        ref = first.arena.P.clone()
+        first.close()
+        assert first.graph_ar is None and first.plans[bs].graphs == {}, "communicator and its captured steps are gone"
+        second = run(4)                       # builds its own communicator and captures while `first` is still alive
+        assert second.graph_ar is not None and torch.equal(second.arena.P, ref)
+        # the closed engine still steps: it emits and captures again, now over torch.distributed between segments
+        first.step(bs)
+        first.step(bs)
+        first.step(bs)
+        torch.cuda.synchronize()
+        assert sum(1 for it in first.plans[bs].graphs[True] if not hasattr(it, "launch")) == 5
+        second.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def _stop_worker(rank, world, port, work_dir, case):
+    import signal
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", RANKAAE_DP_BACKEND="gloo")
+    import torch.distributed as dist
+    import test_engine_gpu as T
+    from rankaae_amd.parameter import Parameters
+    from rankaae_amd.trainer import Trainer
+    g, cfg, spec, aux = T.load_case(case)
+    cfg = dict(cfg, max_epoch=100000, batch_size=32, seed=5)
+    torch.manual_seed(g["model_seed"])
+
+    class Log:
+        def info(self, msg):
+            pass
+    tr = Trainer.from_data(None, igpu=0, verbose=False, work_dir=work_dir, config_parameters=Parameters(cfg),
+                           logger=Log(), loss_logger=Log(), arrays=(spec, aux))
+    seen = []
+    # what rankaae_amd.cmd.train_sc.run_training installs under WORLD_SIZE > 1 -- on ONE rank only here (rank 1):
+    # the other rank has no timer at all and must still come down
+    if rank == 1:
+        signal.signal(signal.SIGALRM, lambda signum, frame: tr.request_stop("Training Overtime!"))
+        signal.setitimer(signal.ITIMER_REAL, 1.0)
+    t0 = time.time()
+    try:
+        tr.train(callback=lambda ep, m: seen.append(ep))
+        raised = None
+    except Exception as e:      # noqa: BLE001 -- the reference raises a bare Exception (sc/cmd/train_sc.py:21-22)
+        raised = str(e)
+    elapsed = time.time() - t0
+    box = [None] * world
+    dist.all_gather_object(box, (raised, len(seen)))
+    assert all(b_[0] == "Training Overtime!" for b_ in box), box
+    assert box[0][1] == box[1][1] and 1 <= box[0][1] < 100000, box      # same epoch on every rank, long before the end
+    assert elapsed < 120
+    assert tr.engine.graph_ar is None and not tr._gc_frozen              # train()'s finally ran
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_timeout_on_one_rank_stops_every_rank(tmp_path):
+    """under data parallelism the per-trial timeout (reference: SIGALRM raises "Training
+    Overtime!", sc/cmd/train_sc.py:21-22,91-97) fires on ONE rank; raising there alone would leave the other rank
+    waiting in the next all-reduce.  The handler now asks the trainer to stop, the flag is OR-reduced beside the
+    per-epoch metrics broadcast, and both ranks raise the reference's exception after the same epoch."""
+    import torch.multiprocessing as mp
+    mp.spawn(_stop_worker, args=(2, _free_port(), str(tmp_path), "fc_small"), nprocs=2, join=True)
+
+
+def _sharded_val_worker(rank, world, port, case):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import test_engine_gpu as T
+    from oracle import ref_train
+    from rankaae_amd import model as pm
+    from rankaae_amd.engine import StepEngine
+    g, cfg, spec, aux = T.load_case(case)
+    cfg = dict(cfg, batch_size=cfg["batch_size"] // world)
+    torch.manual_seed(g["model_seed"])
+    cls = pm.AE_CLS_DICT[cfg["ae_form"]]
+    enc = cls["encoder"](nstyle=cfg["nstyle"], dropout_rate=cfg["dropout_rate"], dim_in=cfg["dim_in"], n_layers=cfg["n_layers"])
+    dec = cls["decoder"](nstyle=cfg["nstyle"], dropout_rate=cfg["dropout_rate"], last_layer_activation=cfg["decoder_activation"],
+                         dim_out=cfg["dim_out"], n_layers=cfg["n_layers"])
+    dis = pm.DiscriminatorFC(nstyle=cfg["nstyle"], dropout_rate=cfg["dis_dropout_rate"], noise=cfg["dis_noise"],
+                             layers=cfg["FC_discriminator_layers"])
+    eng = StepEngine(enc, dec, dis, cfg, T.DEV, rng_mode="host", use_graph=True, world_size=world, rank=rank)
+    n_train, n_val, _ = ref_train.split_rows(len(spec))
+    eng.set_data(spec[:n_train], aux[:n_train])
+    b = cfg["batch_size"]
+    eng.set_epoch(torch.randperm(n_train, generator=torch.Generator().manual_seed(11)), 0.3, start=rank * b, stride=world * b)
+    torch.manual_seed(5 + rank)
+    for _ in range(2):                              # BatchNorm running statistics away from their initial values
+        eng.step(b)
+    bufs = [b_ for mod in (eng.enc_mod, eng.dec_mod) for n_, b_ in mod.named_buffers() if "running" in n_]
+    eng.average_over_ranks(bufs)
+    # an ODD number of validation rows: the two shards differ in size
+    nv = n_val - (1 - n_val % 2)
+    vs = torch.tensor(spec[n_train:n_train + nv], dtype=torch.float32, device=T.DEV)
+    va = torch.tensor(aux[n_train:n_train + nv], dtype=torch.float32, device=T.DEV)
+    out = {}
+    for shard in (False, True, True):
+        eng.cfg["shard_validation"] = shard
+        torch.manual_seed(99)                       # same z_sample / z_real draws in every call and on every rank
+        z, losses = eng.validate(vs, va)
+        out.setdefault(shard, []).append((z.cpu().clone(), losses, eng.val_style_metrics()))
+    rep, sh = out[False][0], out[True]
+    for z, losses, (w, rho) in sh:
+        assert torch.equal(z, rep[0])
+        for k, v in rep[1].items():
+            tol = 1e-6 * abs(v) + 1e-9
+            assert abs(losses[k] - v) <= tol, (k, losses[k], v)
+        assert (w == rep[2][0]).all() and (rho == rep[2][1]).all()
+    # ... and identical on every rank
+    box = [None] * world
+    dist.all_gather_object(box, sh[-1][1])
+    assert box[0] == box[1], box
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["fc_small", "compact_small"])
+def test_sharded_validation_equals_replicated(case):
+    """under data parallelism every rank pairs ITS rows of the validation set with all rows
+    (``raae_rank_rows_pairs``), the per-descriptor totals are summed over the ranks and ``raae_rank_rows_finish`` forms
+    the rank loss -- equal to the replicated ``raae_rank_loss_fwd_bwd`` over the whole set to 1e-6 (the counts are
+    exact integers, the sums float64), with the other four losses, the styles and the style metrics untouched."""
+    import torch.multiprocessing as mp
+    mp.spawn(_sharded_val_worker, args=(2, _free_port(), case), nprocs=2, join=True)

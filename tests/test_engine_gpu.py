@@ -87,6 +87,13 @@ INLINE_CASES = {
 }
 
 
+# Ceilings on the use of P2's escape hatches (see _p2): fraction / floor of gradient tensors that may need the float64
+# arbiter, tensors that may need the kink-adjusted arbiter, near-zero PReLU inputs it may account for.
+P2_CEILINGS = {
+    "default": dict(arbiter_frac=0.05, arbiter_min=2, kink=2, kink_entries=16),
+}
+
+
 def load_case(case):
     if case in INLINE_CASES:
         c = INLINE_CASES[case]
@@ -138,15 +145,20 @@ def test_p1_first_step_matches_reference_golden(case):
     got = eng.losses()
     keys = [k for k in KEYS if not (k == "smooth" and not smooth)]
     base, bound = ref_train.derived_bounds(cfg, g["model_seed"], spec, aux, keys)
+    tight, loose = ref_train.constraining(base, bound, keys)
     report = []
     for k in keys:
         if k in ("adversarial", "kendall"):     # computed before any ill-conditioned update: the reference's own value
             rel_close(got[k], g["loss_calls"][k][0], 1e-4, f"{case} step-1 {k} vs reference golden")
         err = abs(got[k] - base[k])
         report.append(f"{k}: hip {got[k]:.7g} oracle {base[k]:.7g} golden {g['loss_calls'][k][0]:.7g} "
-                      f"|hip-oracle| {err:.2e} bound {bound[k]:.2e}")
-        assert err <= bound[k], f"{case} step-1 {k}: |hip - oracle| = {err:.3e} exceeds the derived bound " \
-                                f"{bound[k]:.3e} (3 x the oracle's own one-ulp sensitivity + 1e-4 rel)"
+                      f"|hip-oracle| {err:.2e} bound {bound[k]:.2e}" +
+                      ("" if k in tight else f"  [bound is {bound[k] / abs(base[k]):.0%} of the value: not constraining, "
+                                             "not asserted; this phase is pinned by P2 / P4]"))
+        if k in tight:
+            assert err <= bound[k], f"{case} step-1 {k}: |hip - oracle| = {err:.3e} exceeds the derived bound " \
+                                    f"{bound[k]:.3e} (3 x the oracle's own one-ulp sensitivity + 1e-4 rel)"
+    assert "adversarial" in tight and "kendall" in tight
     print(f"\n{case} P1: " + "\n  ".join(report))
 
 
@@ -408,6 +420,7 @@ def _p2(case, steps, use_graph):
                 bad.append(f"step {k} loss {key}: hip {got[key]!r} ref {want[key]!r}")
         g64 = None              # float64 repeat of this step, made on demand
         g64_kink = {}
+        hatch = {"tensors": 0, "arbiter": 0, "kink": 0, "kink_entries": 0, "rank_flip": int(rank_flip)}
 
         def kink_adjusted(name):
             """float64 gradients of phase ``name`` with every PReLU branch HIP took differently from the oracle
@@ -452,7 +465,9 @@ def _p2(case, steps, use_graph):
                 report.append((err / (scale + 1e-30), f"{name} {names_e[id(p_e)]} err {err:.2e} |g|inf {scale:.2e} "
                                                       f"phase max {phase_max:.2e} at {int((mine_g - ref_g).abs().argmax())}"
                                                       f"/{mine_g.numel()}"))
+                hatch["tensors"] += 1
                 if err > tol * scale + 1e-5 * phase_max + 1e-7 and g_o is not None:
+                    hatch["arbiter"] += 1
                     if g64 is None:
                         g64 = oracle_float64_gradients(spec, aux, cfg, pre_state, dict(o_post), tape, rows, alpha0,
                                                        members)
@@ -473,8 +488,10 @@ def _p2(case, steps, use_graph):
                         continue
                     # Last arbiter, for PReLU branches fp32 cannot decide: the float64 gradients of the same step
                     # with the branches HIP took at inputs that are rounding noise around zero (kink_adjusted).
+                    hatch["kink"] += 1
                     if name not in g64_kink:
                         g64_kink[name] = kink_adjusted(name)
+                        hatch["kink_entries"] += len(g64_kink[name][1])
                     adj, took = g64_kink[name]
                     if adj is not None and adj[ip] is not None:
                         e_hip = float((mine_g - adj[ip]).abs().max())
@@ -490,6 +507,19 @@ def _p2(case, steps, use_graph):
         if os.environ.get("RAAE_P2_REPORT"):       # debugging aid: the largest relative gradient errors
             print(f"\n{case} step {k}: " + "\n  ".join(f"{r:.2e} {what}" for r, what in sorted(report, reverse=True)[:int(os.environ.get('RAAE_P2_REPORT'))]))
         assert not bad, f"{case}:\n" + "\n".join(bad[:40])
+        # How hard the comparison had to try: the escape hatches above are each justified, but a
+        # regression that pushes many tensors through them must FAIL, not pass silently.  Ceilings per case from the
+        # measured counts (P2_CEILINGS) with headroom; everything else: float64 arbiter for at most 5 % of the tensors
+        # (at least 2), kink-adjusted arbiter for at most 2 tensors and 16 near-zero PReLU inputs.
+        ceil = dict(P2_CEILINGS.get(case, P2_CEILINGS["default"]))
+        ceil_arb = max(ceil["arbiter_min"], int(ceil["arbiter_frac"] * hatch["tensors"]))
+        print(f"\n{case} step {k} graph={use_graph} P2 escape hatches: {hatch['tensors']} gradient tensors, "
+              f"{hatch['arbiter']} needed the float64 arbiter (ceiling {ceil_arb}), {hatch['kink']} the kink-adjusted "
+              f"arbiter (ceiling {ceil['kink']}) over {hatch['kink_entries']} near-zero PReLU inputs (ceiling "
+              f"{ceil['kink_entries']}), rank-loss pair flip: {bool(hatch['rank_flip'])}")
+        if os.environ.get("RAAE_P2_NO_CEILING") != "1":
+            assert hatch["arbiter"] <= ceil_arb, (case, k, hatch)
+            assert hatch["kink"] <= ceil["kink"] and hatch["kink_entries"] <= ceil["kink_entries"], (case, k, hatch)
         # BN running statistics follow the oracle's (momentum updates of 6 enc / 4 dec forwards)
         for mod_e, mod_o in ((eng.enc_mod, tr.encoder), (eng.dec_mod, tr.decoder)):
             sd = mod_o.state_dict()
@@ -521,6 +551,66 @@ def test_graph_replay_is_bitwise_eager(case):
         assert torch.equal(results[0][2], other[2])
         assert results[0][1] == other[1]
     assert all(np.isfinite(v) for v in results[0][1].values())
+
+
+@pytest.mark.parametrize("case,over", [("fc_small", {}), ("fc_example", {}), ("compact_small", {}),
+                                       ("fc_b4096", {"n_steps": 2})])
+def test_inline_masks_equal_tape_masks(case, over):
+    """in ``rng_mode: philox`` the kernels that apply dropout regenerate their multipliers from a
+    counter-based hash keyed by (seed, step, element) instead of reading a fp32 tape (``inline_masks``, default on).
+    ``raae_rng_fill`` evaluates the same function for slots that stay on the tape, and every slot keeps its position in
+    the numbering whether it is resident or not: with ``inline_masks: false`` (everything on the tape) the run is BIT
+    FOR BIT the same -- weights, Adam moments, BatchNorm statistics, losses -- eagerly and as graph replay."""
+    g, cfg, spec, aux = load_case(case)
+    bs = cfg["batch_size"]
+    out = []
+    for inline in (True, False):
+        eng = build_engine(dict(cfg, inline_masks=inline), 4321, spec, aux, use_graph=True, rng_mode="philox")
+        assert eng.inline_masks == inline
+        n_train = len(eng.train_spec)
+        eng.set_epoch(torch.randperm(n_train, generator=torch.Generator().manual_seed(3)), 0.25)
+        for _ in range(over.get("n_steps", 4)):
+            eng.step(bs)
+        torch.cuda.synchronize()
+        P = eng.plan(bs)
+        out.append(([eng.arena.P.clone()] + [b_.clone() for mod in (eng.enc_mod, eng.dec_mod) for b_ in mod.buffers()] +
+                    [o.v.clone() for o in eng.opts.values()], eng.losses(), P.tape.total))
+    for a, b in zip(out[0][0], out[1][0]):
+        assert torch.equal(a, b), "in-kernel dropout multipliers differ from the tape's"
+    assert out[0][1] == out[1][1]
+    if cfg["ae_form"] == "FC":
+        assert out[0][2] < out[1][2], "the dense networks' multipliers should have left the tape"
+
+
+def test_dropout_hash_statistics():
+    """The counter-based hash behind the dropout multipliers (raae_common.h): over 2^22 elements of one step the
+    keep fraction is keep +- 4 sigma, two steps and two seeds are uncorrelated (|corr| < 4 / sqrt(n)), and the
+    multiplier is exactly 1 / keep."""
+    from rankaae_amd.engine import Tape
+    n, keep = 1 << 22, 0.9
+    t = Tape()
+    off = t.slot(n, 1, keep)
+    t.finalize(DEV)
+    ctr = torch.zeros(1, dtype=torch.int64, device=DEV)
+    draws = []
+    for seed, step in ((7, 1), (7, 2), (8, 1)):
+        ctr.fill_(step)
+        ops.rng_fill(t.buf, t.seg_desc, t.seg_scale, len(t.segs), t.total, seed, ctr)
+        draws.append(t.view(off, n).clone())
+    sig = (keep * (1 - keep) / n) ** 0.5
+    for d in draws:
+        vals = torch.unique(d).tolist()
+        assert len(vals) == 2 and vals[0] == 0.0 and abs(vals[1] - float(np.float32(1.0) / np.float32(keep))) < 1e-7
+        assert abs(float((d != 0).double().mean()) - keep) < 4 * sig
+    for a, b in ((0, 1), (0, 2), (1, 2)):
+        x, y = (draws[a] != 0).double(), (draws[b] != 0).double()
+        corr = float(((x - x.mean()) * (y - y.mean())).mean() / (x.std() * y.std()))
+        assert abs(corr) < 4 / n ** 0.5, (a, b, corr)
+    # neighbouring elements are uncorrelated too (lag 1, 64, 4096)
+    x = (draws[0] != 0).double()
+    for lag in (1, 64, 4096):
+        corr = float(((x[:-lag] - x.mean()) * (x[lag:] - x.mean())).mean() / x.var())
+        assert abs(corr) < 4 / n ** 0.5, (lag, corr)
 
 
 def test_one_row_batch_raises_like_the_reference():

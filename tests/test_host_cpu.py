@@ -129,6 +129,9 @@ def _dp_worker(rank, world, port, out):
     g = torch.full((64,), float(rank + 1))
     allreduce_mean_(g)
     ok_mean = bool(torch.allclose(g, torch.full((64,), (world + 1) / 2.0)))
+    # the stop flag of a data-parallel run (Trainer.request_stop): raised on ONE rank, seen by all
+    from rankaae_amd.parallel import any_rank
+    ok_mean = ok_mean and any_rank(rank == 1, torch.device("cpu")) and not any_rank(False, torch.device("cpu"))
     if rank == 0:
         out.put((nb, ok_cover, ok_mean))
     dist.destroy_process_group()

@@ -79,13 +79,16 @@ def test_trainer_end_to_end(case, rng_mode, tmp_path):
                              for a, b in itertools.combinations(range(len(zc)), 2)], rtol=0, atol=1e-12)
 
 
-@pytest.mark.parametrize("case", ["p3_fc", "p3_compact"])
-def test_p3_statistical_parity(case, tmp_path):
+@pytest.mark.parametrize("case,precision", [("p3_fc", "fp32"), ("p3_compact", "fp32"), ("p3_fc", "bf16")])
+def test_p3_statistical_parity(case, precision, tmp_path):
     """SURVEY 8d protocol P3: the trajectory is chaotic, so beyond teacher-forced steps the comparison is
     statistical -- 8 model seeds x 6 epochs; the distribution of the final validation reconstruction MSE,
     mean training mutual-information loss and validation rank loss of this engine (device Philox noise) must
     overlap the real reference's (fixtures: oracle/gen_golden.py p3_*): difference of means within
-    3 standard errors + 10 %."""
+    3 standard errors + 10 %.  ``precision: bf16`` (BASELINE configs[4]'s mixed precision: bf16 STORAGE of the dense
+    networks' hidden activations and dropout flags, fp32 arithmetic) is held to the SAME reference distribution and
+    the same bound: its per-step gradients are 2-25 % from the fp32 engine's (test_bf16_storage_mode_fc_512_aux12), and
+    this is the test that says whether that matters for training."""
     import logging
     from rankaae_amd.parameter import Parameters
     from rankaae_amd.trainer import Trainer
@@ -99,7 +102,7 @@ def test_p3_statistical_parity(case, tmp_path):
     got = []
     for r in g["runs"]:
         cfg = dict(g["config"])
-        cfg.update(rng_mode="philox", seed=r["model_seed"])
+        cfg.update(rng_mode="philox", seed=r["model_seed"], precision=precision)
         torch.manual_seed(r["model_seed"])
         wd = tmp_path / f"s{r['model_seed']}"
         wd.mkdir()
@@ -113,8 +116,10 @@ def test_p3_statistical_parity(case, tmp_path):
         se = np.sqrt((ref[:, j].var(ddof=1) + got[:, j].var(ddof=1)) / n)
         diff = abs(got[:, j].mean() - ref[:, j].mean())
         assert diff <= 3 * se + 0.1 * abs(ref[:, j].mean()), \
-            f"{case} {name}: ours {got[:, j].mean():.5f}+-{got[:, j].std(ddof=1):.5f} vs reference " \
+            f"{case} {precision} {name}: ours {got[:, j].mean():.5f}+-{got[:, j].std(ddof=1):.5f} vs reference " \
             f"{ref[:, j].mean():.5f}+-{ref[:, j].std(ddof=1):.5f}"
+        print(f"\n{case} {precision} {name}: ours {got[:, j].mean():.5f}+-{got[:, j].std(ddof=1):.5f} vs reference "
+              f"{ref[:, j].mean():.5f}+-{ref[:, j].std(ddof=1):.5f} (allowed difference of means {3 * se + 0.1 * abs(ref[:, j].mean()):.5f})")
     # Shapiro W and the coupling metric live in [0, 1]; same ballpark
     assert abs(got[:, 0].mean() - ref[:, 0].mean()) < 0.15 and abs(got[:, 3].mean() - ref[:, 3].mean()) < 0.25
 
