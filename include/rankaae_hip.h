@@ -448,6 +448,21 @@ int raae_step_tick(int* steps, int n, unsigned mask, unsigned long long* rng_cou
 int raae_rng_fill(float* tape, const int* seg_desc, const float* seg_scale, int nseg, long total,
                   unsigned long long seed, const unsigned long long* counter, void* stream);
 
+/* The head of a training step in one launch: raae_step_tick + raae_rng_fill + raae_gather_batch (trainer.py:106-113: the
+ * DataLoader's next batch, ``spec_in += randn_like(spec_in) * spec_noise``).  rng_state (device) = {step counter, seed};
+ * the launch works with counter + 1 and cursor + stride and its last workgroup stores them (and steps[i] += 1 for the
+ * bits of step_mask) for the kernels that follow.  noise_tape: the noise slot of a host-filled tape (parity mode) or
+ * NULL: N(0, 1) generated in the kernel at position noise_goff of the step's Gaussian numbering -- bit for bit what
+ * raae_rng_fill writes for that slot.  nseg > 0: the tape's resident slots are filled as by raae_rng_fill.
+ * ticket: device unsigned, zero before the first call. */
+typedef struct {
+    int* steps; int nsteps; unsigned step_mask; unsigned long long* rng_state; int* cursor; int stride; unsigned* ticket;
+    const float* spec; const float* aux; const long* idx; int B, L, n_aux; float spec_noise;
+    const float* noise_tape; long noise_goff; float* spec_out; float* aux_out;
+    float* tape; const int* seg_desc; const float* seg_scale; int nseg; long total;
+} raae_step_begin_t;
+int raae_step_begin(const raae_step_begin_t* p, void* stream);
+
 /* ---- stream / graph / event plumbing (HIP runtime; used by the engine and bench.py) ---- */
 int raae_graph_begin(void* stream);
 int raae_graph_end(void* stream, void** graph_exec);

@@ -245,6 +245,11 @@ __device__ __forceinline__ void stat_jobs(const StatJob (&jobs)[N], bool is_bloc
             }
             continue;
         }
+        // workgroup 0 updates the running statistics: their loads are issued BEFORE the sweep of the partial rows and
+        // used after it (as a read-modify-write behind the reduction they were one more dependent round trip of the
+        // workgroup that ends the kernel last)
+        const bool upd = is_block0 && jb.update && jb.rm != nullptr && lane < jb.C;
+        const float rm0 = upd ? jb.rm[lane] : 0.f, rv0 = upd ? jb.rv[lane] : 0.f;
         int cp = 1;
         while (cp < jb.C) cp <<= 1;
         const int J = 64 / cp, c = lane & (cp - 1), j = lane / cp;
@@ -276,11 +281,11 @@ __device__ __forceinline__ void stat_jobs(const StatJob (&jobs)[N], bool is_bloc
                 // double like ATen's CPU accumulate type: a float rstd moves PReLU-slope gradients of the
                 // compact fixture by 2% (ill-conditioned sums), see DESIGN.md
                 jb.o2[lane] = (float)(1.0 / sqrt(var + (double)jb.eps));
-                if (is_block0 && jb.update && jb.rm != nullptr) {
+                if (upd) {
                     const double n_ = (double)jb.count;
                     const double unb = n_ > 1.0 ? var * n_ / (n_ - 1.0) : var;
-                    jb.rm[lane] = (float)((1.0 - jb.momentum) * (double)jb.rm[lane] + jb.momentum * mean);
-                    jb.rv[lane] = (float)((1.0 - jb.momentum) * (double)jb.rv[lane] + jb.momentum * unb);
+                    jb.rm[lane] = (float)((1.0 - jb.momentum) * (double)rm0 + jb.momentum * mean);
+                    jb.rv[lane] = (float)((1.0 - jb.momentum) * (double)rv0 + jb.momentum * unb);
                 }
             } else {
                 jb.o1[lane] = (float)(s * inv);
@@ -340,9 +345,18 @@ template <int N>
 __device__ __forceinline__ void stat_jobs_wide(const StatJob (&jobs)[N], bool is_block0) {
     __shared__ double2 scr[N][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int D = N >= 3 ? 4 : 8;                 // loads in flight per job and lane
+    constexpr int D = 4;                              // loads in flight per job and lane (first batch)
     double2 v[N][D];
     int cpv[N], cv[N], phv[N];
+    // running statistics of the job this thread will finish (wave n finishes job n): loaded now, used at the end
+    float rm0 = 0.f, rv0 = 0.f;
+    bool upd = false;
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+        if (n == wave && jobs[n].kind == 0 && jobs[n].partials != nullptr && is_block0 && jobs[n].update &&
+            jobs[n].rm != nullptr && lane < jobs[n].C) {
+            upd = true; rm0 = jobs[n].rm[lane]; rv0 = jobs[n].rv[lane];
+        }
 #pragma unroll
     for (int n = 0; n < N; ++n) {
         const StatJob& jb = jobs[n];
@@ -410,11 +424,11 @@ __device__ __forceinline__ void stat_jobs_wide(const StatJob (&jobs)[N], bool is
                         if (var < 0.0) var = 0.0;
                         jb.o1[lane] = (float)mean;
                         jb.o2[lane] = (float)(1.0 / sqrt(var + (double)jb.eps));
-                        if (is_block0 && jb.update && jb.rm != nullptr) {
+                        if (upd) {
                             const double n_ = (double)jb.count;
                             const double unb = n_ > 1.0 ? var * n_ / (n_ - 1.0) : var;
-                            jb.rm[lane] = (float)((1.0 - jb.momentum) * (double)jb.rm[lane] + jb.momentum * mean);
-                            jb.rv[lane] = (float)((1.0 - jb.momentum) * (double)jb.rv[lane] + jb.momentum * unb);
+                            jb.rm[lane] = (float)((1.0 - jb.momentum) * (double)rm0 + jb.momentum * mean);
+                            jb.rv[lane] = (float)((1.0 - jb.momentum) * (double)rv0 + jb.momentum * unb);
                         }
                     } else {
                         jb.o1[lane] = (float)(s * inv);

@@ -13,6 +13,23 @@
 #include "raae_common.h"
 #include <hip/hip_bf16.h>
 
+#ifdef RAAE_STAMPS
+// per-instance stage clocks of workgroup 0 (100 MHz), summed over all launches: tools/dense_stamps.py
+__device__ unsigned long long d_dense_sum[8][12], d_dense_cnt[8][12];
+__device__ long long d_dense_prev[8];
+#define DSTAMP(slot, i) do { __syncthreads(); if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { \
+        const long long now_ = wall_clock64(); \
+        if ((i) > 0) { d_dense_sum[slot][i] += (unsigned long long)(now_ - d_dense_prev[slot]); d_dense_cnt[slot][i] += 1ull; } \
+        d_dense_prev[slot] = now_; } } while (0)
+extern "C" int raae_debug_dense_stamps(unsigned long long* sum, unsigned long long* cnt) {
+    hipError_t e = hipMemcpyFromSymbol(sum, HIP_SYMBOL(d_dense_sum), sizeof(unsigned long long) * 8 * 12);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipMemcpyFromSymbol(cnt, HIP_SYMBOL(d_dense_cnt), sizeof(unsigned long long) * 8 * 12);
+}
+#else
+#define DSTAMP(slot, i) do { } while (0)
+#endif
+
 namespace {
 
 using raae::prelu;
@@ -57,7 +74,11 @@ __device__ __forceinline__ float in_transform(float v, int k, int in_kind, const
 // hash generator (raae_common.h), or nowhere.
 struct MaskSrc {
     const float* ptr; bool bf; float scale; bool gen; raae::MaskGen g;
+    unsigned long long seed, ctr; unsigned off; float keep;      // generator: raw state, requested early (arm), keyed late (key)
     __device__ __forceinline__ bool any() const { return gen || ptr != nullptr; }
+    // the generator's keys from the state words requested by mask_src(): called where the multipliers are first needed,
+    // BEHIND the statistic prologue -- deriving them at once would put the state's round trip in front of every other load
+    __device__ __forceinline__ void key() { if (gen) g = raae::mask_gen_make(seed, ctr, off, keep); }
     __device__ __forceinline__ float4 at4(size_t o) const {        // o a multiple of 4
         if (gen) return raae::mask_val4(g, (uint32_t)o);
         if (bf) { const float4 m = bf16x4_at(ptr, o); return make_float4(m.x * scale, m.y * scale, m.z * scale, m.w * scale); }
@@ -74,14 +95,16 @@ __device__ __forceinline__ MaskSrc mask_src(const float* mask, int in_kind, int 
     m.bf = (storage & RAAE_ST_MASK) != 0;
     m.scale = scale != 0.f ? scale : 1.f;
     m.gen = in_kind != RAAE_IN_NONE && gen.state != nullptr;
-    if (m.gen) m.g = raae::mask_gen_from(gen);
+    m.seed = 0ull; m.ctr = 0ull; m.off = gen.offset; m.keep = gen.keep;
+    if (m.gen) { m.ctr = gen.state[0]; m.seed = gen.state[1]; }
     return m;
 }
 
-// One 16-row tile of a layer input as NV float4 per thread (K % 4 == 0): thread t holds float4 number t + 256 u of the
-// tile, i.e. (row f / kq, columns 4 (f % kq) ..).  The raw values and their dropout multipliers are LOADED here and
-// transformed / stored to LDS later, so that the loads of a tile are in flight during the statistic prologue (first
-// tile) or the previous tile's matrix work (following tiles).
+// A tile of ROWS = 16 RT rows of a layer input as NV float4 per thread (K % 4 == 0): thread t holds float4 number
+// t + 256 u of the tile, i.e. (row f / kq, columns 4 (f % kq) ..).  The raw values and their dropout multipliers are
+// LOADED here and transformed / stored to LDS later, so that the loads of a tile are in flight during the statistic
+// prologue (first tile) or the previous tile's matrix work (following tiles).
+// (K: the row stride of x and of the multipliers' numbering; k0: first column of this workgroup's slice of the row)
 template <int NV>
 struct RawTile { float4 x[NV]; float4 m[NV]; };
 
@@ -94,56 +117,60 @@ __device__ __forceinline__ void tile_coords(int kq, int (&rr)[NV], int (&cc)[NV]
         cc[u] = (f - rr[u] * kq) << 2;
     }
 }
-// (K: the row stride of x and of the multipliers' numbering; k0: first column of this workgroup's slice of the row)
 template <int NV>
-__device__ __forceinline__ void tile_load(RawTile<NV>& t, const int (&rr)[NV], const int (&cc)[NV], const float* x, bool xb,
-                                          const MaskSrc& ms, int row0, int B, int K, int k0 = 0) {
+__device__ __forceinline__ void tile_load(RawTile<NV>& t, const int (&rr)[NV], const int (&cc)[NV], int rows,
+                                          const float* x, bool xb, const MaskSrc& ms, int row0, int B, int K, int k0 = 0) {
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
         const int row = row0 + rr[u];
         t.x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         t.m[u] = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (rr[u] < 16 && row < B) {
+        if (rr[u] < rows && row < B) {
             const size_t o = (size_t)row * K + k0 + cc[u];
             t.x[u] = xb ? bf16x4_at(x, o) : *reinterpret_cast<const float4*>(x + o);
-            if (ms.any()) t.m[u] = ms.at4(o);
+            if (ms.ptr != nullptr) t.m[u] = ms.at4(o);       // (generated multipliers: tile_store, no memory involved)
         }
     }
 }
 // transform -> Xs (x * mask); optionally the pre-dropout value -> Ys and the multiplier -> Ms (backward epilogue)
 template <int NV>
-__device__ __forceinline__ void tile_store(const RawTile<NV>& t, const int (&rr)[NV], const int (&cc)[NV], float* Xs, float* Ys,
-                                           float* Ms, int pitch, int in_kind, const float* s_slope, const float* s_mean,
-                                           const float* s_rstd) {
+__device__ __forceinline__ void tile_store(const RawTile<NV>& t, const int (&rr)[NV], const int (&cc)[NV], int rows,
+                                           float* Xs, float* Ys, float* Ms, int pitch, int in_kind, const float* s_slope,
+                                           const float* s_mean, const float* s_rstd, const MaskSrc& ms, int row0, int B,
+                                           int K, int k0 = 0) {
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
-        if (rr[u] >= 16) continue;
+        if (rr[u] >= rows) continue;
         const int k = cc[u];
         float4 v = t.x[u];
         v.x = in_transform(v.x, k, in_kind, s_slope, s_mean, s_rstd);
         v.y = in_transform(v.y, k + 1, in_kind, s_slope, s_mean, s_rstd);
         v.z = in_transform(v.z, k + 2, in_kind, s_slope, s_mean, s_rstd);
         v.w = in_transform(v.w, k + 3, in_kind, s_slope, s_mean, s_rstd);
-        const float4 m = t.m[u];
         const int o = rr[u] * pitch + k;               // pitch even => 8-byte aligned
         if (Ys != nullptr) {
             reinterpret_cast<float2*>(Ys + o)[0] = make_float2(v.x, v.y);
             reinterpret_cast<float2*>(Ys + o)[1] = make_float2(v.z, v.w);
         }
-        if (Ms != nullptr) {
-            reinterpret_cast<float2*>(Ms + o)[0] = make_float2(m.x, m.y);
-            reinterpret_cast<float2*>(Ms + o)[1] = make_float2(m.z, m.w);
+        if (ms.any()) {
+            float4 m = t.m[u];
+            if (ms.gen) m = (row0 + rr[u] < B) ? ms.at4((size_t)(row0 + rr[u]) * K + k0 + k) : make_float4(1.f, 1.f, 1.f, 1.f);
+            if (Ms != nullptr) {
+                reinterpret_cast<float2*>(Ms + o)[0] = make_float2(m.x, m.y);
+                reinterpret_cast<float2*>(Ms + o)[1] = make_float2(m.z, m.w);
+            }
+            v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
         }
-        reinterpret_cast<float2*>(Xs + o)[0] = make_float2(v.x * m.x, v.y * m.y);
-        reinterpret_cast<float2*>(Xs + o)[1] = make_float2(v.z * m.z, v.w * m.w);
+        reinterpret_cast<float2*>(Xs + o)[0] = make_float2(v.x, v.y);
+        reinterpret_cast<float2*>(Xs + o)[1] = make_float2(v.z, v.w);
     }
 }
 
 // The same for any K (a decoder's first layer has K = nstyle = 6): element by element, zero padded to KP columns.
-__device__ __forceinline__ void stage_rows_scalar(float* Xs, float* Ys, float* Ms, int pitch, const float* x, bool xb,
+__device__ __forceinline__ void stage_rows_scalar(float* Xs, float* Ys, float* Ms, int pitch, int rows, const float* x, bool xb,
                                                   const MaskSrc& ms, int row0, int B, int K, int KP, int in_kind,
                                                   const float* s_slope, const float* s_mean, const float* s_rstd) {
-    for (int idx = threadIdx.x; idx < 16 * KP; idx += 256) {
+    for (int idx = threadIdx.x; idx < rows * KP; idx += 256) {
         const int r = idx / KP, k = idx - r * KP;
         const int row = row0 + r;
         float v = 0.f, m = 1.f;
@@ -158,15 +185,21 @@ __device__ __forceinline__ void stage_rows_scalar(float* Xs, float* Ys, float* M
     }
 }
 
-// dynamic LDS: s_mean[K4] s_rstd[K4] s_slope[K4] | Xs[16][pitch].  The wave's 16 output columns of W
+// dynamic LDS: s_mean[K4] s_rstd[K4] s_slope[K4] | Xs[16 RT][pitch].  The wave's 16 output columns of W
 // stay in registers (KQ floats per lane = the B operands of all K/4 MFMA steps) across its row tiles.
 // (bx, by) of a (gx, *) grid: the workgroup's tile / column-block index (the whole grid of dense_fwd_kernel, one of
 // the two ranges of dense_fwd2_kernel)
+// RT: 16-row tiles per pass.  RT = 4 (batches of >= 2048 rows): 64 rows are loaded, staged and multiplied together --
+//     four independent accumulator chains per wave instead of one, one exposed memory round trip per 64 rows instead of
+//     one per 16 (a tile takes less time than the prefetch of the next one needs), a quarter of the workgroups, i.e. of
+//     the partial-statistic rows every consumer reduces.
 // ST: instance that honours a.storage (bf16 storage); the fp32 instances (ST false) carry none of its branches
-template <int KQ, bool ST = false>
-__device__ __forceinline__ void dense_fwd_body(const DenseFwdArgs& a, const int bx, const int by, const int gx, float* smem) {
+template <int KQ, int RT, bool ST>
+__device__ __forceinline__ void dense_fwd_tiles(const DenseFwdArgs& a, const int bx, const int by, const int gx, float* smem,
+                                                MaskSrc& ms) {
     const int st = ST ? a.storage : 0;
-    constexpr int NV = KQ >= 64 ? KQ / 16 : 1;       // float4s per thread of a 16-row tile (K <= 4 KQ)
+    constexpr int NV = (KQ >= 64 ? KQ / 16 : 1) * RT;      // float4s per thread of a 16 RT-row tile (K <= 4 KQ)
+    constexpr int ROWS = 16 * RT;
     const int K4 = (a.K + 3) & ~3;
     float* s_mean = smem;
     float* s_rstd = s_mean + K4;
@@ -175,22 +208,52 @@ __device__ __forceinline__ void dense_fwd_body(const DenseFwdArgs& a, const int 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int col = by * 64 + wv * 16 + (lane & 15);
     const bool vec = (a.K & 3) == 0, xb = (st & RAAE_ST_X) != 0;
-    const int ntiles = (a.B + 15) >> 4;
+    const int ntiles = (a.B + ROWS - 1) / ROWS;
+    constexpr int SLOT = KQ == 4 ? 0 : (KQ == 16 ? 1 : (KQ == 64 ? 2 : 3));
+    (void)SLOT;
+    DSTAMP(SLOT, 0);
 
-    float wreg[KQ];
+    // every global operand of the prologue is requested before any is used: the workgroup's weight block, the first
+    // tile's raw input (and multipliers), the PReLU slopes of the input, bias and output slope -- and, inside
+    // stat_jobs_wide, the partial statistics and the running statistics workgroup 0 updates.
+    // Weights: the 64 x K block of the workgroup's output columns goes through LDS (KQ <= 64) -- 16-byte loads of
+    // consecutive addresses; a lane fetching its own B operands W[col][4 q + lane / 16] straight from memory made
+    // every load instruction touch 16 rows (7.7 of the 13 us of the 256 -> 64 first layer at 256 rows).  The 512-column
+    // first layer (KQ = 128: 132 KB) keeps the register form.
+    constexpr bool WLDS = KQ <= 64;
+    constexpr int NW = WLDS ? (KQ >= 16 ? KQ / 4 : 1) : 1;      // float4s of the weight block per thread
+    const int pitchW = K4 + 4;
+    float* Ws = Xs + ROWS * a.pitch;
+    float wreg[WLDS ? 1 : KQ];
+    float4 wraw[NW];
+    if (!WLDS) {
 #pragma unroll
-    for (int q = 0; q < KQ; ++q) {
-        const int k = 4 * q + (lane >> 4);
-        wreg[q] = (col < a.N && k < a.K) ? a.w[(size_t)col * a.K + k] : 0.f;
+        for (int q = 0; q < (WLDS ? 1 : KQ); ++q) {
+            const int k = 4 * q + (lane >> 4);
+            wreg[q] = (col < a.N && k < a.K) ? a.w[(size_t)col * a.K + k] : 0.f;
+        }
+    } else if (vec) {
+        const int kq = a.K >> 2;
+#pragma unroll
+        for (int u = 0; u < NW; ++u) {
+            const int f = tid + 256 * u, c = f / kq, k4 = f - c * kq;
+            wraw[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < 64 && by * 64 + c < a.N) wraw[u] = *reinterpret_cast<const float4*>(a.w + (size_t)(by * 64 + c) * a.K + 4 * k4);
+        }
     }
-    const MaskSrc ms = mask_src(a.mask, a.in_kind, st, a.mask_scale, a.gen);
-    // the first tile's raw input and multipliers: in flight during the statistic prologue
     int rr[NV], cc[NV];
     RawTile<NV> raw;
     if (vec) {
         tile_coords<NV>(a.K >> 2, rr, cc);
-        tile_load<NV>(raw, rr, cc, a.x, xb, ms, bx << 4, a.B, a.K);
+        tile_load<NV>(raw, rr, cc, ROWS, a.x, xb, ms, bx * ROWS, a.B, a.K);
     }
+    float slope_pre[2] = {0.f, 0.f};
+    if (a.in_kind != RAAE_IN_NONE) {
+        if (tid < a.K) slope_pre[0] = a.slope[tid];
+        if (tid + 256 < a.K) slope_pre[1] = a.slope[tid + 256];
+    }
+    const float bias = (col < a.N) ? a.bias[col] : 0.f;
+    const float oslope = (a.out_kind == RAAE_OUT_STATS_PRELU && col < a.N) ? a.out_slope[col] : 1.f;
     if (a.in_kind == RAAE_IN_PRELU_BN_DROP) {
         if (a.K <= 64) {            // all four waves sweep the partial rows (raae_common.h)
             const raae::StatJob jobs[1] = {raae::stat_job_bn(a.bn, a.K, s_mean, s_rstd, true)};
@@ -199,52 +262,84 @@ __device__ __forceinline__ void dense_fwd_body(const DenseFwdArgs& a, const int 
             raae::bn_prologue(a.bn, a.K, s_mean, s_rstd, bx == 0 && by == 0);
         }
     }
-    if (a.in_kind != RAAE_IN_NONE)
-        for (int k = tid; k < a.K; k += 256) s_slope[k] = a.slope[k];
+    if (a.in_kind != RAAE_IN_NONE) {
+        if (tid < a.K) s_slope[tid] = slope_pre[0];
+        if (tid + 256 < a.K) s_slope[tid + 256] = slope_pre[1];
+    }
+    if (WLDS) {
+        if (vec) {
+            const int kq = a.K >> 2;
+#pragma unroll
+            for (int u = 0; u < NW; ++u) {
+                const int f = tid + 256 * u, c = f / kq, k4 = f - c * kq;
+                if (c < 64) *reinterpret_cast<float4*>(Ws + c * pitchW + 4 * k4) = wraw[u];
+            }
+        } else {
+            for (int idx = tid; idx < 64 * K4; idx += 256) {
+                const int c = idx / K4, k = idx - c * K4;
+                Ws[c * pitchW + k] = (by * 64 + c < a.N && k < a.K) ? a.w[(size_t)(by * 64 + c) * a.K + k] : 0.f;
+            }
+        }
+    }
+    ms.key();
     __syncthreads();
+    DSTAMP(SLOT, 1);
 
-    const float bias = (col < a.N) ? a.bias[col] : 0.f;
-    const float oslope = (a.out_kind == RAAE_OUT_STATS_PRELU && col < a.N) ? a.out_slope[col] : 1.f;
     double s_acc = 0.0, q_acc = 0.0;
     const float* xa = Xs + (lane & 15) * a.pitch + (lane >> 4);
+    const float* wb = Ws + (wv * 16 + (lane & 15)) * pitchW + (lane >> 4);
 
     for (int tile = bx; tile < ntiles; tile += gx) {
-        const int row0 = tile << 4;
+        const int row0 = tile * ROWS;
         if (vec) {
-            tile_store<NV>(raw, rr, cc, Xs, nullptr, nullptr, a.pitch, a.in_kind, s_slope, s_mean, s_rstd);
+            tile_store<NV>(raw, rr, cc, ROWS, Xs, nullptr, nullptr, a.pitch, a.in_kind, s_slope, s_mean, s_rstd, ms,
+                                 row0, a.B, a.K);
             if (tile + gx < ntiles)       // the next tile's loads fly during this tile's matrix work and stores
-                tile_load<NV>(raw, rr, cc, a.x, xb, ms, (tile + gx) << 4, a.B, a.K);
+                tile_load<NV>(raw, rr, cc, ROWS, a.x, xb, ms, (tile + gx) * ROWS, a.B, a.K);
         } else {
-            stage_rows_scalar(Xs, nullptr, nullptr, a.pitch, a.x, xb, ms, row0, a.B, a.K, K4, a.in_kind, s_slope, s_mean, s_rstd);
+            stage_rows_scalar(Xs, nullptr, nullptr, a.pitch, ROWS, a.x, xb, ms, row0, a.B, a.K, K4, a.in_kind, s_slope, s_mean, s_rstd);
         }
         __syncthreads();
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        DSTAMP(SLOT, 2);
+        f32x4 acc[RT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < KQ; ++q)
-            if (4 * q < K4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[4 * q], wreg[q], acc, 0, 0, 0);
+            if (4 * q < K4) {
+                const float bq = WLDS ? wb[4 * q] : wreg[WLDS ? 0 : q];
+#pragma unroll
+                for (int t = 0; t < RT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[t * 16 * a.pitch + 4 * q], bq, acc[t], 0, 0, 0);
+            }
         __syncthreads();
-        // epilogue: lane holds rows row0 + (lane>>4)*4 + j of column `col`
+        DSTAMP(SLOT, 3);
+        // epilogue: lane holds rows row0 + 16 t + (lane>>4)*4 + j of column `col`
         if (col < a.N) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = row0 + (lane >> 4) * 4 + j;
-                if (row < a.B) {
-                    float zv = acc[j] + bias;
-                    if (st & RAAE_ST_Z) zv = bf16_round(zv);
-                    float o = zv;
-                    if (a.out_kind == RAAE_OUT_SOFTPLUS) o = raae::softplus2(zv);
-                    else if (a.out_kind == RAAE_OUT_RELU) o = fmaxf(zv, 0.f);
-                    if (st & RAAE_ST_Z) bf16_store(a.z, (size_t)row * a.N + col, o);
-                    else a.z[(size_t)row * a.N + col] = o;
-                    if (a.out_kind == RAAE_OUT_STATS_PRELU || a.out_kind == RAAE_OUT_STATS_RAW) {
-                        const float v = (a.out_kind == RAAE_OUT_STATS_PRELU) ? prelu(zv, oslope) : zv;
-                        s_acc += (double)v;
-                        q_acc += (double)v * (double)v;
+            for (int t = 0; t < RT; ++t) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = row0 + t * 16 + (lane >> 4) * 4 + j;
+                    if (row < a.B) {
+                        float zv = acc[t][j] + bias;
+                        if (st & RAAE_ST_Z) zv = bf16_round(zv);
+                        float o = zv;
+                        if (a.out_kind == RAAE_OUT_SOFTPLUS) o = raae::softplus2(zv);
+                        else if (a.out_kind == RAAE_OUT_RELU) o = fmaxf(zv, 0.f);
+                        if (st & RAAE_ST_Z) bf16_store(a.z, (size_t)row * a.N + col, o);
+                        else a.z[(size_t)row * a.N + col] = o;
+                        if (a.out_kind == RAAE_OUT_STATS_PRELU || a.out_kind == RAAE_OUT_STATS_RAW) {
+                            const float v = (a.out_kind == RAAE_OUT_STATS_PRELU) ? prelu(zv, oslope) : zv;
+                            s_acc += (double)v;
+                            q_acc += (double)v * (double)v;
+                        }
                     }
                 }
             }
         }
     }
+    DSTAMP(SLOT, 4);
     if (a.out_kind == RAAE_OUT_STATS_PRELU || a.out_kind == RAAE_OUT_STATS_RAW) {
         s_acc += __shfl_xor(s_acc, 16, 64); q_acc += __shfl_xor(q_acc, 16, 64);
         s_acc += __shfl_xor(s_acc, 32, 64); q_acc += __shfl_xor(q_acc, 32, 64);
@@ -253,19 +348,26 @@ __device__ __forceinline__ void dense_fwd_body(const DenseFwdArgs& a, const int 
             p[0] = s_acc; p[1] = q_acc;
         }
     }
+    DSTAMP(SLOT, 5);
 }
 
-template <int KQ, bool ST = false>
+template <int KQ, int RT = 1, bool ST = false>
+__device__ __forceinline__ void dense_fwd_body(const DenseFwdArgs& a, const int bx, const int by, const int gx, float* smem) {
+    MaskSrc ms = mask_src(a.mask, a.in_kind, ST ? a.storage : 0, a.mask_scale, a.gen);
+    dense_fwd_tiles<KQ, RT, ST>(a, bx, by, gx, smem, ms);
+}
+
+template <int KQ, int RT = 1, bool ST = false>
 __global__ __launch_bounds__(256) void dense_fwd_kernel(DenseFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    dense_fwd_body<KQ, ST>(a, blockIdx.x, blockIdx.y, gridDim.x, smem);
+    dense_fwd_body<KQ, RT, ST>(a, blockIdx.x, blockIdx.y, gridDim.x, smem);
 }
 
 // Two independent layers (one of the encoder, one of the decoder: the forward chain whose result the reference
 // discards beside one that is needed) in ONE launch: workgroups [0, n1) run the first, the rest the second.
 struct DenseFwd2Args { DenseFwdArgs x; DenseFwdArgs y; int n1; int gx1; int gx2; };
 template <int Q1, int Q2>
-__global__ __launch_bounds__(256) void dense_fwd2_kernel(DenseFwd2Args k) {
+__global__ __launch_bounds__(256, 1) void dense_fwd2_kernel(DenseFwd2Args k) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int b = blockIdx.x;
     if (b < k.n1) {
@@ -286,31 +388,71 @@ struct DenseBwdArgs {
     int kw;       // input columns per workgroup: blockIdx.y owns columns [y kw, (y + 1) kw) of x, dW and dx (kw == K: all)
 };
 
-// TPW: 16x16 dW tiles per wave; KT4: 16-column dx tiles per wave (= float4s per thread of an input tile).
-// NQ: 16 -> N <= 64 (a thread owns one output column and four rows of a tile), 64 -> N <= 256, 0 -> N <= 512 (a thread
-//     owns its column(s) over all 16 rows); for NQ > 0 the W operands of the dx product (N16/4 x KT4 floats per lane)
-//     stay in registers across the row tiles.
+// Stage a 16-row tile of the layer input into LDS (transform applied, zero padded to K4 columns).
+// Vector path (K % 4 == 0): one float4 per thread per pass, no integer division in the loop.
+// (backward kernel; Kl columns from column k0 of rows of stride K; ms: where the dropout multipliers come from)
+__device__ __forceinline__ void stage_rows(float* Xs, int pitch, const float* x, const MaskSrc& ms, int row0, int B,
+                                           int K, int k0, int Kl, int K4, int in_kind, const float* s_slope,
+                                           const float* s_mean, const float* s_rstd, int storage = 0) {
+    const int tid = threadIdx.x;
+    const bool xb = (storage & RAAE_ST_X) != 0;
+    if ((Kl & 3) == 0 && (K & 3) == 0) {
+        const int kq = Kl >> 2;                      // float4s per row
+        int r = tid / kq, c4 = tid - r * kq;
+        const int dr = 256 / kq, dc = 256 - dr * kq;
+        for (; r < 16; ) {
+            const int row = row0 + r, k = c4 << 2;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < B) {
+                const size_t o = (size_t)row * K + k0 + k;
+                v = xb ? bf16x4_at(x, o) : *reinterpret_cast<const float4*>(x + o);
+                v.x = in_transform(v.x, k, in_kind, s_slope, s_mean, s_rstd);
+                v.y = in_transform(v.y, k + 1, in_kind, s_slope, s_mean, s_rstd);
+                v.z = in_transform(v.z, k + 2, in_kind, s_slope, s_mean, s_rstd);
+                v.w = in_transform(v.w, k + 3, in_kind, s_slope, s_mean, s_rstd);
+                if (ms.any()) {
+                    const float4 m = ms.at4(o);
+                    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+                }
+            }
+            float2* dst = reinterpret_cast<float2*>(Xs + r * pitch + k);     // pitch even => 8-B aligned
+            dst[0] = make_float2(v.x, v.y);
+            dst[1] = make_float2(v.z, v.w);
+            r += dr; c4 += dc;
+            if (c4 >= kq) { c4 -= kq; ++r; }
+        }
+    } else {
+        for (int idx = tid; idx < 16 * K4; idx += 256) {
+            const int r = idx / K4, k = idx - r * K4;
+            const int row = row0 + r;
+            float v = 0.f;
+            if (row < B && k < Kl) {
+                const size_t o = (size_t)row * K + k0 + k;
+                v = in_transform(xb ? bf16_at(x, o) : x[o], k, in_kind, s_slope, s_mean, s_rstd);
+                if (ms.any()) v *= ms.at(o);
+            }
+            Xs[r * pitch + k] = v;
+        }
+    }
+}
+
+
+// TPW: 16x16 dW tiles per wave; KT4: 16-column dx tiles per wave.
 // LDS: o_mean[N16] o_rstd[N16] o_slope[N16] m1[N16] m2[N16] | i_mean[K16] i_rstd[K16] i_slope[K16]
-//      | Gs[16][pitch_g] | Xs[16][pitch_x] | Ys[16][pitch_x] | Ms[16][pitch_x] | red[2][256]
-// The raw operands of a row tile (dL/dy, the stored output, the layer input, its multipliers) are LOADED into registers
-// one tile ahead: during the statistic prologue for the first tile (one round trip instead of four dependent ones: the
-// row loop of the gradient staging used to wait for every row), during the matrix work for the following ones.
-template <int TPW, int KT4, int NQ, bool ST = false>
+//      | Gs[16][pitch_g] | Xs[16][pitch_x] | red[2][256]
+// (round 3: a rewrite that carried every operand one tile ahead in registers, kept the dx weights in registers and
+// batched four row tiles measured SLOWER in the step -- 11.9 against 10.5 us for the 64 x 64 layer at 256 rows, 26.7
+// against 24.3 at 4096 -- and is not kept; what is kept from it: the column slices of a first layer, dropout
+// multipliers generated in the kernel, slopes requested before the statistic prologue.)
+// A first layer (K = 256 / 512 input points, no input transform) is split over blockIdx.y in slices of kw columns: more
+// workgroups for the launch-bound batches and a dW tile set of 8 tiles per wave (19.4 -> 12.0 us at 256 rows).
+template <int TPW, int KT4, bool ST = false>
 __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int st = ST ? a.storage : 0;
-    constexpr bool WIDE = NQ != 16;                  // N > 64
-    constexpr int H = NQ == 0 ? 2 : 1;               // column sets per thread
-    constexpr int GR = WIDE ? 16 : 4;                // rows of a tile per thread and column
-    constexpr int NV = KT4;
-    constexpr bool WREGS = NQ > 0 && KT4 * NQ <= 64;   // W operands of the dx product in registers (else: from memory)
-    // the widest shapes (512-point first / last layer) have no registers to carry a tile ahead: they load where they stage
-    constexpr bool XPRE = KT4 < 8, GPRE = NQ != 0;
-    // A first layer (K = 256 / 512 input points, no input transform) is split over blockIdx.y in slices of kw columns:
-    // more workgroups for the launch-bound batches, and a dW tile set that fits the registers (the unsplit 512-column
-    // instance spilled).  Kl: this workgroup's columns, k0: the first of them.
-    const int k0 = blockIdx.y * a.kw, Kl = a.kw;
+    const int k0 = blockIdx.y * a.kw, Kl = a.kw;      // this workgroup's input columns [k0, k0 + Kl)
     const int N16 = (a.N + 15) & ~15, K16 = (Kl + 15) & ~15;
+    MaskSrc ms = mask_src(a.mask, a.in_kind, st, a.mask_scale, a.gen);
     float* o_mean = smem;
     float* o_rstd = o_mean + N16;
     float* o_slope = o_rstd + N16;
@@ -321,68 +463,18 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
     float* i_slope = i_rstd + K16;
     float* Gs = i_slope + K16;
     float* Xs = Gs + 16 * a.pitch_g;
-    float* Ys = Xs + 16 * a.pitch_x;
-    float* Ms = Ys + 16 * a.pitch_x;
-    float* red = Ms + 16 * a.pitch_x;
+    float* red = Xs + 16 * a.pitch_x;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int NT = N16 >> 4, KT = K16 >> 4;
-    const bool vec = (Kl & 3) == 0 && (a.K & 3) == 0, xb = (st & RAAE_ST_X) != 0, zb = (st & RAAE_ST_Z) != 0;
-    const bool need_y = a.dx != nullptr && a.dx_partials != nullptr;
-    const MaskSrc ms = mask_src(a.mask, a.in_kind, st, a.mask_scale, a.gen);
-    const bool need_m = a.dx != nullptr && ms.any();
-    const int ntiles = (a.B + 15) >> 4;
-
-    // ---- W operands of the dx product: registers (loads in flight during the prologue) ----
-    float wdx[WREGS ? KT4 : 1][WREGS ? NQ : 1];
-    if (WREGS && a.dx != nullptr) {
-#pragma unroll
-        for (int i = 0; i < (WREGS ? KT4 : 1); ++i) {
-            const int kcol = (wv + 4 * i) * 16 + (lane & 15);
-#pragma unroll
-            for (int u = 0; u < (WREGS ? NQ : 1); ++u) {
-                const int n = 4 * u + (lane >> 4);
-                wdx[i][u] = (kcol < Kl && n < a.N) ? a.w[(size_t)n * a.K + k0 + kcol] : 0.f;
-            }
-        }
-    }
-    // ---- the first tile's raw operands ----
-    // G: thread owns column(s) n = tid (+256) when N > 64, else n = tid % 64 with row phase tid / 64
-    const int gcol0 = WIDE ? tid : (tid & 63);
-    const int grow0 = WIDE ? 0 : (tid >> 6);
-    constexpr int grstep = WIDE ? 1 : 4;
-    float gq[H][GR], zq[H][GR];
-    auto g_load = [&](int row0) {
-#pragma unroll
-        for (int h = 0; h < H; ++h) {
-            const int n = gcol0 + h * 256;
-#pragma unroll
-            for (int j = 0; j < GR; ++j) {
-                const int row = row0 + grow0 + j * grstep;
-                gq[h][j] = 0.f; zq[h][j] = 0.f;
-                if (row < a.B && n < a.N) {
-                    const size_t o = (size_t)row * a.N + n;
-                    gq[h][j] = a.g[o];
-                    if (a.g_kind != RAAE_G_DIRECT) zq[h][j] = (zb && a.g_kind != RAAE_G_SOFTPLUS && a.g_kind != RAAE_G_RELU) ? bf16_at(a.zout, o) : a.zout[o];
-                }
-            }
-        }
-    };
-    int rr[NV], cc[NV];
-    RawTile<NV> raw;
-    if (GPRE) g_load(blockIdx.x << 4);
-    if (vec && XPRE) {
-        tile_coords<NV>(Kl >> 2, rr, cc);
-        tile_load<NV>(raw, rr, cc, a.x, xb, ms, blockIdx.x << 4, a.B, a.K, k0);
-    }
 
     const bool g_bn = a.g_kind == RAAE_G_PRELU_BN, i_bn = a.in_kind == RAAE_IN_PRELU_BN_DROP;
     if ((!g_bn || a.N <= 64) && (!i_bn || a.K <= 64)) {
-        // the three statistic reductions together, every one spread over the four waves
+        // the three statistic reductions side by side, one wave each (they used to run one after the other)
         const raae::StatJob jobs[3] = {
             g_bn ? raae::stat_job_bn(a.out_bn, a.N, o_mean, o_rstd, false) : raae::stat_job_none(),
             g_bn ? raae::stat_job_bwd(a.g_partials, a.g_nparts, a.N, a.out_bn.count, m1, m2) : raae::stat_job_none(),
             i_bn ? raae::stat_job_bn(a.bn, a.K, i_mean, i_rstd, false) : raae::stat_job_none()};
-        raae::stat_jobs_wide<3>(jobs, false);
+        raae::stat_jobs<3>(jobs, false);
     } else {
         if (g_bn) {
             raae::bn_prologue(a.out_bn, a.N, o_mean, o_rstd, false);
@@ -394,6 +486,7 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
         for (int n = tid; n < a.N; n += 256) o_slope[n] = a.out_slope[n];
     if (a.in_kind != RAAE_IN_NONE)
         for (int k = tid; k < Kl; k += 256) i_slope[k] = a.slope[k0 + k];
+    ms.key();
     __syncthreads();
 
     f32x4 wacc[TPW];
@@ -402,44 +495,34 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
     double dxs[KT4], dxq[KT4];
 #pragma unroll
     for (int i = 0; i < KT4; ++i) { dxs[i] = 0.0; dxq[i] = 0.0; }
-    double db_acc[H], ds_acc[H];
-#pragma unroll
-    for (int h = 0; h < H; ++h) { db_acc[h] = 0.0; ds_acc[h] = 0.0; }
+    // G staging: thread owns column(s) n = tid (+256) when N > 64, else n = tid % 64 with row phase tid/64
+    const bool wideN = a.N > 64;
+    const int gcol0 = wideN ? tid : (tid & 63);
+    const int grow0 = wideN ? 0 : (tid >> 6);
+    const int grstep = wideN ? 1 : 4;
+    double db_acc[2] = {0.0, 0.0}, ds_acc[2] = {0.0, 0.0};
 
+    const bool zb = (st & RAAE_ST_Z) != 0;
+    const int ntiles = (a.B + 15) >> 4;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile << 4;
-        const bool more = tile + (int)gridDim.x < ntiles;
-        if (!GPRE) g_load(row0);
-        if (!XPRE && vec) {            // widest shapes: two float4s at a time, staged at once
-#pragma unroll 1
-            for (int c0 = 0; c0 < NV; c0 += 2) {
-                RawTile<2> part;
-                int r2[2], c2[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int f = tid + 256 * (c0 + u), kq = Kl >> 2;
-                    r2[u] = f / kq; c2[u] = (f - r2[u] * kq) << 2;
-                }
-                tile_load<2>(part, r2, c2, a.x, xb, ms, row0, a.B, a.K, k0);
-                tile_store<2>(part, r2, c2, Xs, need_y ? Ys : nullptr, need_m ? Ms : nullptr, a.pitch_x, a.in_kind, i_slope,
-                              i_mean, i_rstd);
-            }
-        }
         // ---- 1. dL/dz tile -> Gs (zero padded) ----
 #pragma unroll
-        for (int h = 0; h < H; ++h) {
+        for (int h = 0; h < 2; ++h) {
             const int n = gcol0 + h * 256;
+            if (h == 1 && !(wideN && n < N16)) break;
             if (n >= N16) continue;
-#pragma unroll
-            for (int j = 0; j < GR; ++j) {
-                const int r = grow0 + j * grstep, row = row0 + r;
+            for (int r = grow0; r < 16; r += grstep) {
+                const int row = row0 + r;
                 float dz = 0.f;
                 if (row < a.B && n < a.N) {
-                    const float gv = gq[h][j], zv = zq[h][j];
+                    const size_t o = (size_t)row * a.N + n;
+                    const float gv = a.g[o];
                     if (a.g_kind == RAAE_G_DIRECT) dz = gv;
-                    else if (a.g_kind == RAAE_G_SOFTPLUS) dz = gv * (1.f - expf(-2.f * zv));
-                    else if (a.g_kind == RAAE_G_RELU) dz = zv > 0.f ? gv : 0.f;
+                    else if (a.g_kind == RAAE_G_SOFTPLUS) dz = gv * (1.f - expf(-2.f * a.zout[o]));
+                    else if (a.g_kind == RAAE_G_RELU) dz = a.zout[o] > 0.f ? gv : 0.f;
                     else {
+                        const float zv = zb ? bf16_at(a.zout, o) : a.zout[o];
                         float da = gv;
                         if (a.g_kind == RAAE_G_PRELU_BN) {
                             const float y = (prelu(zv, o_slope[n]) - o_mean[n]) * o_rstd[n];
@@ -453,21 +536,8 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
                 Gs[r * a.pitch_g + n] = dz;
             }
         }
-        // ---- 2. layer input tile -> Xs (transform applied; Ys / Ms for the dx epilogue) ----
-        if (vec && XPRE) tile_store<NV>(raw, rr, cc, Xs, need_y ? Ys : nullptr, need_m ? Ms : nullptr, a.pitch_x, a.in_kind,
-                                        i_slope, i_mean, i_rstd);
-        else if (!vec) stage_rows_scalar(Xs, need_y ? Ys : nullptr, need_m ? Ms : nullptr, a.pitch_x, a.x, xb, ms, row0, a.B, a.K, K16,
-                                         a.in_kind, i_slope, i_mean, i_rstd);       // (never split: kw == K)
-        if (vec && K16 != Kl) {        // zero the padding columns K .. K16 (K % 16 != 0, K % 4 == 0)
-            for (int idx = tid; idx < 16 * (K16 - Kl); idx += 256) {
-                const int r = idx / (K16 - Kl), k = Kl + idx - r * (K16 - Kl);
-                Xs[r * a.pitch_x + k] = 0.f;
-            }
-        }
-        if (more) {                    // the next tile's operands fly during this tile's matrix work
-            if (GPRE) g_load((tile + gridDim.x) << 4);
-            if (XPRE && vec) tile_load<NV>(raw, rr, cc, a.x, xb, ms, (tile + gridDim.x) << 4, a.B, a.K, k0);
-        }
+        // ---- 2. layer input tile -> Xs (transform applied) ----
+        stage_rows(Xs, a.pitch_x, a.x, ms, row0, a.B, a.K, k0, Kl, K16, a.in_kind, i_slope, i_mean, i_rstd, st);
         __syncthreads();
         // ---- 3. dW[n][k] += sum_rows dz[row][n] * xin[row][k]; wave owns tiles t = wv + 4 i ----
 #pragma unroll
@@ -476,10 +546,10 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
             if (t < NT * KT) {
                 const int tn = t / KT, tk = t - tn * KT;
                 const float* ga = Gs + (lane >> 4) * a.pitch_g + tn * 16 + (lane & 15);
-                const float* xbp = Xs + (lane >> 4) * a.pitch_x + tk * 16 + (lane & 15);
+                const float* xb = Xs + (lane >> 4) * a.pitch_x + tk * 16 + (lane & 15);
 #pragma unroll
                 for (int r4 = 0; r4 < 16; r4 += 4)
-                    wacc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[r4 * a.pitch_g], xbp[r4 * a.pitch_x], wacc[i], 0, 0, 0);
+                    wacc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[r4 * a.pitch_g], xb[r4 * a.pitch_x], wacc[i], 0, 0, 0);
             }
         }
         // ---- 4. dx[row][k] = (sum_n dz[row][n] W[n][k]) * mask ; partial sums for the input's BN ----
@@ -492,48 +562,43 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
                     const int kcol = tk * 16 + (lane & 15);
                     const float* ga = Gs + (lane & 15) * a.pitch_g + (lane >> 4);
                     const bool kok = kcol < Kl;
-                    if (WREGS) {
+                    // B operand W[n][kcol]: 16 independent loads in flight per group of 16 MFMA steps
+                    const float* wp = a.w + (size_t)(lane >> 4) * a.K + k0 + kcol;
+                    int nn = 0;
+                    for (; nn + 64 <= N16; nn += 64) {
+                        float bb[16];
 #pragma unroll
-                        for (int u = 0; u < (WREGS ? NQ : 1); ++u)
-                            if (4 * u < N16) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[4 * u], wdx[WREGS ? i : 0][u], acc, 0, 0, 0);
-                    } else {
-                        // B operand W[n][kcol] from memory: 16 independent loads in flight per group of 16 MFMA steps
-                        const float* wp = a.w + (size_t)(lane >> 4) * a.K + k0 + kcol;
-                        int nn = 0;
-                        for (; nn + 64 <= N16; nn += 64) {
-                            float bb[16];
-#pragma unroll
-                            for (int u = 0; u < 16; ++u) {
-                                const int n = nn + 4 * u + (lane >> 4);
-                                bb[u] = (kok && n < a.N) ? wp[(size_t)(nn + 4 * u) * a.K] : 0.f;
-                            }
-#pragma unroll
-                            for (int u = 0; u < 16; ++u)
-                                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[nn + 4 * u], bb[u], acc, 0, 0, 0);
+                        for (int u = 0; u < 16; ++u) {
+                            const int n = nn + 4 * u + (lane >> 4);
+                            bb[u] = (kok && n < a.N) ? wp[(size_t)(nn + 4 * u) * a.K] : 0.f;
                         }
-                        for (; nn < N16; nn += 16) {
-                            float bb[4];
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const int n = nn + 4 * u + (lane >> 4);
-                                bb[u] = (kok && n < a.N) ? wp[(size_t)(nn + 4 * u) * a.K] : 0.f;
-                            }
+                        for (int u = 0; u < 16; ++u)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[nn + 4 * u], bb[u], acc, 0, 0, 0);
+                    }
+                    for (; nn < N16; nn += 16) {
+                        float bb[4];
 #pragma unroll
-                            for (int u = 0; u < 4; ++u)
-                                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[nn + 4 * u], bb[u], acc, 0, 0, 0);
+                        for (int u = 0; u < 4; ++u) {
+                            const int n = nn + 4 * u + (lane >> 4);
+                            bb[u] = (kok && n < a.N) ? wp[(size_t)(nn + 4 * u) * a.K] : 0.f;
                         }
-                        __builtin_amdgcn_sched_barrier(0);     // keep the next column tile's 16 loads out of this one's registers
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[nn + 4 * u], bb[u], acc, 0, 0, 0);
                     }
                     if (kok) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const int r = (lane >> 4) * 4 + j, row = row0 + r;
+                            const int row = row0 + (lane >> 4) * 4 + j;
                             if (row < a.B) {
+                                const size_t o = (size_t)row * a.K + k0 + kcol;
                                 float d = acc[j];
-                                if (need_m) d *= Ms[r * a.pitch_x + kcol];
-                                a.dx[(size_t)row * a.K + k0 + kcol] = d;
-                                if (need_y) {
-                                    const float y = Ys[r * a.pitch_x + kcol];
+                                if (ms.any()) d *= ms.at(o);
+                                a.dx[o] = d;
+                                if (a.dx_partials != nullptr) {
+                                    const float xv = (st & RAAE_ST_X) ? bf16_at(a.x, o) : a.x[o];
+                                    const float y = (prelu(xv, i_slope[kcol]) - i_mean[kcol]) * i_rstd[kcol];
                                     dxs[i] += (double)d;
                                     dxq[i] += (double)d * (double)y;
                                 }
@@ -563,9 +628,9 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
     }
     // db / dslope: combine the row-phase copies of each column in fixed order (the first column slice writes them)
     if (blockIdx.y != 0) {
-    } else if (WIDE) {
+    } else if (wideN) {
 #pragma unroll
-        for (int h = 0; h < H; ++h) {
+        for (int h = 0; h < 2; ++h) {
             const int n = tid + h * 256;
             if (n < a.N) {
                 a.db[slab + n] = (float)db_acc[h];
@@ -603,8 +668,10 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
 // batches use FEWER, longer-running workgroups -- 16-row tiles one after the other, the next tile's loads in flight
 // during the current tile's matrix work (256 workgroups of one tile each at 4096 rows meant 256 KB of partials per
 // workgroup: 15 of the 20 us of a 64-wide layer).
-int pick_grid(int B) {
-    const int ntiles = (B + 15) / 16;
+// rt: 16-row tiles per pass of a workgroup (1, or 4 for batches of >= 2048 rows where the instance exists)
+int pick_rt(int B) { return B >= 2048 ? 4 : 1; }
+int pick_grid(int B, int rt = 1) {
+    const int ntiles = (B + 16 * rt - 1) / (16 * rt);
     int cap = ntiles / 8;
     if (cap > RAAE_MAX_PARTS) cap = RAAE_MAX_PARTS;
     if (cap < 64) cap = 64;
@@ -615,7 +682,8 @@ int pick_grid(int B) {
 
 static int prep_dense_fwd(const float* x, int B, int K, int in_kind, const float* slope, const raae_bn_t* bn,
                           const float* mask, const float* w, const float* bias, int N, float* z, int out_kind,
-                          const float* out_slope, double* out_partials, DenseFwdArgs& a, dim3& grid, size_t& lds, int& kq) {
+                          const float* out_slope, double* out_partials, DenseFwdArgs& a, dim3& grid, size_t& lds, int& kq,
+                          bool allow_rt = true) {
     RAAE_CHECK_ARG(x && w && bias && z && B > 0 && K > 0 && N > 0 && K <= 512);
     RAAE_CHECK_ARG(in_kind >= 0 && in_kind <= 2 && out_kind >= 0 && out_kind <= 4);
     RAAE_CHECK_ARG(in_kind == RAAE_IN_NONE || slope);
@@ -633,24 +701,31 @@ static int prep_dense_fwd(const float* x, int B, int K, int in_kind, const float
     const int K4 = (K + 3) & ~3;
     RAAE_CHECK_ARG(K4 <= 512 && (in_kind != RAAE_IN_PRELU_BN_DROP || K <= 256));
     a.pitch = K4 + 2;
-    lds = sizeof(float) * (3 * (size_t)K4 + 16 * (size_t)a.pitch);
-    grid = dim3(pick_grid(B), (N + 63) / 64);
     kq = K4 <= 16 ? 4 : K4 <= 64 ? 16 : K4 <= 256 ? 64 : 128;
+    // 64-row passes for the large batches (not the 512-column layer: its tile would not fit the registers)
+    const int rt = (allow_rt && kq <= 64) ? pick_rt(B) : 1;
+    lds = sizeof(float) * (3 * (size_t)K4 + 16 * (size_t)rt * (size_t)a.pitch + (kq <= 64 ? 64 * ((size_t)K4 + 4) : 0));
+    grid = dim3(pick_grid(B, rt), (N + 63) / 64, rt);       // (grid.z carries rt to launch_dense_fwd; launched with z = 1)
     return 0;
 }
 
 static void launch_dense_fwd(const DenseFwdArgs& a, dim3 grid, size_t lds, int kq, hipStream_t st) {
-    if (a.storage) {        // bf16 storage: the hidden layers of the dense networks (K <= 64 -> KQ 16; first layer KQ 64 / 128)
-        if (kq == 4) hipLaunchKernelGGL((dense_fwd_kernel<4, true>), grid, dim3(256), lds, st, a);
-        else if (kq == 16) hipLaunchKernelGGL((dense_fwd_kernel<16, true>), grid, dim3(256), lds, st, a);
-        else if (kq == 64) hipLaunchKernelGGL((dense_fwd_kernel<64, true>), grid, dim3(256), lds, st, a);
-        else hipLaunchKernelGGL((dense_fwd_kernel<128, true>), grid, dim3(256), lds, st, a);
-        return;
+    const int rt = (int)grid.z;
+    grid.z = 1;
+#define RAAE_FWD(KQ_, RT_) do { if (a.storage) hipLaunchKernelGGL((dense_fwd_kernel<KQ_, RT_, true>), grid, dim3(256), lds, st, a); \
+                               else hipLaunchKernelGGL((dense_fwd_kernel<KQ_, RT_, false>), grid, dim3(256), lds, st, a); } while (0)
+    // bf16 storage (a.storage): the hidden layers of the dense networks (K <= 64 -> KQ 16; first layer KQ 64 / 128)
+    if (rt == 4) {
+        if (kq == 4) RAAE_FWD(4, 4);
+        else if (kq == 16) RAAE_FWD(16, 4);
+        else RAAE_FWD(64, 4);
+    } else {
+        if (kq == 4) RAAE_FWD(4, 1);
+        else if (kq == 16) RAAE_FWD(16, 1);
+        else if (kq == 64) RAAE_FWD(64, 1);
+        else RAAE_FWD(128, 1);
     }
-    if (kq == 4) hipLaunchKernelGGL(dense_fwd_kernel<4>, grid, dim3(256), lds, st, a);
-    else if (kq == 16) hipLaunchKernelGGL(dense_fwd_kernel<16>, grid, dim3(256), lds, st, a);
-    else if (kq == 64) hipLaunchKernelGGL(dense_fwd_kernel<64>, grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL(dense_fwd_kernel<128>, grid, dim3(256), lds, st, a);
+#undef RAAE_FWD
 }
 
 extern "C" int raae_dense_fwd(const float* x, int B, int K, int in_kind, const float* slope, const raae_bn_t* bn,
@@ -694,10 +769,10 @@ extern "C" int raae_dense_fwd2(const raae_dense_fwd_t* p, const raae_dense_fwd_t
     size_t l1, l2;
     int q1, q2;
     int rc = prep_dense_fwd(p->x, p->B, p->K, p->in_kind, p->slope, p->has_bn ? &p->bn : nullptr, p->mask, p->w, p->bias,
-                            p->N, p->z, p->out_kind, p->out_slope, p->out_partials, k.x, g1, l1, q1);
+                            p->N, p->z, p->out_kind, p->out_slope, p->out_partials, k.x, g1, l1, q1, false);
     if (rc) return rc;
     rc = prep_dense_fwd(q->x, q->B, q->K, q->in_kind, q->slope, q->has_bn ? &q->bn : nullptr, q->mask, q->w, q->bias,
-                        q->N, q->z, q->out_kind, q->out_slope, q->out_partials, k.y, g2, l2, q2);
+                        q->N, q->z, q->out_kind, q->out_slope, q->out_partials, k.y, g2, l2, q2, false);
     if (rc) return rc;
     RAAE_CHECK_ARG(!(p->gen.state && p->mask) && !(q->gen.state && q->mask));
     k.x.storage = p->storage; k.y.storage = q->storage;
@@ -709,6 +784,7 @@ extern "C" int raae_dense_fwd2(const raae_dense_fwd_t* p, const raae_dense_fwd_t
     k.n1 = (int)(g1.x * g1.y); k.gx1 = (int)g1.x; k.gx2 = (int)g2.x;
     const dim3 grid(k.n1 + g2.x * g2.y);
     const size_t lds = l1 > l2 ? l1 : l2;
+    g1.z = 1; g2.z = 1;
     // instances: the layer pairs of the 256-point dense networks (first layers 256 -> 64 beside 6 -> 64, then 64-wide
     // layers beside each other); anything else: two launches
     if (!(p->storage | q->storage) && q1 == 64 && q2 == 4) hipLaunchKernelGGL((dense_fwd2_kernel<64, 4>), grid, dim3(256), lds, st, k);
@@ -781,38 +857,28 @@ extern "C" int raae_dense_bwd_s(const raae_dense_bwd_t* p, int* nslab, void* str
     a.storage = storage; a.mask_scale = p->mask_scale; a.gen = p->gen;
     const int tiles = (N16 / 16) * (K16 / 16);
     const int tpw = (tiles + 3) / 4, kt4 = (K16 / 16 + 3) / 4;
-    const size_t lds = sizeof(float) * (5 * (size_t)N16 + 3 * (size_t)K16 + 16 * (size_t)a.pitch_g + 48 * (size_t)a.pitch_x + 512);
+    const size_t lds = sizeof(float) * (5 * (size_t)N16 + 3 * (size_t)K16 + 16 * (size_t)(a.pitch_g + a.pitch_x) + 512);
     RAAE_CHECK_ARG(lds <= 160 * 1024);
-    // cap the number of slabs: each slab is N*K floats that the Adam kernel re-reads
+    // workgroups = gradient slabs = partial rows of dx: few and long-running at large batches (pick_grid).  Measured at
+    // 4096 rows, dense networks: 64 workgroups of four tiles each make THIS kernel slower (31.7 against 24.3 us for the
+    // 64 x 64 layer with 256 one-tile workgroups) and the step faster (408-442 against 341-356 steps/s): every consumer
+    // of its partial rows sweeps a quarter of them.  Cap the slabs of large layers: the Adam kernel re-reads each.
     int gx = pick_grid(B);
     if ((long)N * K >= 8192 && gx > 64) gx = 64;
     if (nslab) *nslab = gx;
     dim3 grid(gx, K / a.kw), block(256);
     hipStream_t st = (hipStream_t)stream;
     const bool need_dx = p->dx != nullptr;
-    const int nq = N <= 64 ? 16 : (N <= 256 ? 64 : 0);
-#define RAAE_BWD(TPW_, KT4_, NQ_) do { if (storage) hipLaunchKernelGGL((dense_bwd_kernel<TPW_, KT4_, NQ_, true>), grid, block, lds, st, a); \
-                                      else hipLaunchKernelGGL((dense_bwd_kernel<TPW_, KT4_, NQ_, false>), grid, block, lds, st, a); } while (0)
-    // (KT4 also sizes the per-thread input tile: K16 / 64 float4s, so it follows K even when dx is not needed)
-    if (nq == 16) {
-        if (tpw <= 1 && kt4 <= 1) RAAE_BWD(1, 1, 16);
-        else if (tpw <= 4 && kt4 <= 1) RAAE_BWD(4, 1, 16);
-        else if (tpw <= 8 && kt4 <= 2) RAAE_BWD(8, 2, 16);           // a 128-column slice of a first layer
-        else if (tpw <= 16 && kt4 <= 4) RAAE_BWD(16, 4, 16);
-        else if (tpw <= 32 && kt4 <= 8) RAAE_BWD(32, 8, 16);
-        else return RAAE_EINVAL;
-    } else if (nq == 64) {
-        if (tpw <= 4 && kt4 <= 1) RAAE_BWD(4, 1, 64);
-        else if (tpw <= 16 && kt4 <= 1) RAAE_BWD(16, 1, 64);
-        else if (tpw <= 32 && kt4 <= 1) RAAE_BWD(32, 1, 64);
-        else if (tpw <= 32 && kt4 <= 8) RAAE_BWD(32, 8, 0);      // W operands from memory
-        else return RAAE_EINVAL;
-    } else {
-        if (tpw <= 32 && kt4 <= 1) RAAE_BWD(32, 1, 0);
-        else if (tpw <= 32 && kt4 <= 8) RAAE_BWD(32, 8, 0);
-        else return RAAE_EINVAL;
-    }
-    (void)need_dx;
+#define RAAE_BWD(TPW_, KT4_) do { if (storage) hipLaunchKernelGGL((dense_bwd_kernel<TPW_, KT4_, true>), grid, block, lds, st, a); \
+                                 else hipLaunchKernelGGL((dense_bwd_kernel<TPW_, KT4_, false>), grid, block, lds, st, a); } while (0)
+    if (tpw <= 1 && kt4 <= 1) RAAE_BWD(1, 1);
+    else if (tpw <= 4 && kt4 <= 1) RAAE_BWD(4, 1);
+    else if (tpw <= 8 && kt4 <= 2) RAAE_BWD(8, 2);               // a 128-column slice of a first layer
+    else if (tpw <= 16 && (kt4 <= 1 || !need_dx)) RAAE_BWD(16, 1);
+    else if (tpw <= 16 && kt4 <= 4) RAAE_BWD(16, 4);
+    else if (tpw <= 32 && (kt4 <= 1 || !need_dx)) RAAE_BWD(32, 1);
+    else if (tpw <= 32 && kt4 <= 8) RAAE_BWD(32, 8);
+    else return RAAE_EINVAL;
 #undef RAAE_BWD
     RAAE_LAUNCH_RET();
 }

@@ -138,51 +138,126 @@ __device__ __forceinline__ void philox(uint32_t c[4], uint32_t k0, uint32_t k1) 
 }
 __device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
-// tape segments start at multiples of 4 floats; thread i fills floats [4i, 4i+4).
+// four N(0, 1) values: Philox block `qg` (= position in the numbering of the step's Gaussian elements / 4) of step `ctr`
+__device__ __forceinline__ void normal4(long qg, unsigned long long ctr, unsigned long long seed, float (&o)[4]) {
+    uint32_t c[4] = {(uint32_t)qg, (uint32_t)(qg >> 32), (uint32_t)ctr, (uint32_t)(ctr >> 32)};
+    philox(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float r0 = sqrtf(-2.f * logf(u01(c[0]))), r1 = sqrtf(-2.f * logf(u01(c[2])));
+    const float a0 = 6.283185307179586f * u01(c[1]), a1 = 6.283185307179586f * u01(c[3]);
+    o[0] = r0 * cosf(a0); o[1] = r0 * sinf(a0); o[2] = r1 * cosf(a1); o[3] = r1 * sinf(a1);
+}
+
+// floats [4 q, 4 q + 4) of the tape (segments start at multiples of 4 floats)
+__device__ __forceinline__ void fill_quad(float* tape, const int* seg_desc, const float* seg_scale, int nseg, long total,
+                                          unsigned long long seed, unsigned long long ctr, long q) {
+    const long e0 = q * 4;
+    int lo = 0, hi = nseg - 1;
+    while (lo < hi) {                       // last segment whose offset <= e0
+        const int mid = (lo + hi + 1) >> 1;
+        if ((long)seg_desc[mid * 4] <= e0) lo = mid; else hi = mid - 1;
+    }
+    const int kind = seg_desc[lo * 4 + 2];
+    const long send = (long)seg_desc[lo * 4] + seg_desc[lo * 4 + 1];
+    float o[4];
+    if (kind == 0) {
+        // Philox counter = (position of these four floats in the numbering of the step's Gaussian elements) / 4
+        normal4(((long)seg_desc[lo * 4 + 3] + (e0 - seg_desc[lo * 4])) >> 2, ctr, seed, o);
+    } else if (kind == 1) {
+        // dropout multipliers {0, 1/keep}: the counter-based hash of raae_common.h -- the function a kernel with a
+        // raae_maskgen_t evaluates for a slot it generates itself (hash index = the slot's position in the numbering
+        // of ALL dropout elements of the step, seg_desc[.][3], + the element's index in the slot: the same whether the
+        // slot lives on the tape or in its consumer)
+        const raae::MaskGen g = raae::mask_gen_make(seed, ctr, (uint32_t)seg_desc[lo * 4 + 3], seg_scale[lo]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = raae::mask_val(g, (uint32_t)(e0 + j - seg_desc[lo * 4]));
+    } else {
+        // kind 2 (`precision: bf16`): keep flags {0, 1} stored as bf16 -- these four floats hold eight of them (bf16
+        // element i of the slot is hashed at index i of the slot); the dense kernels multiply by the fp32 1/keep
+        const raae::MaskGen g = raae::mask_gen_make(seed, ctr, (uint32_t)seg_desc[lo * 4 + 3], seg_scale[lo]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t e = 2u * (uint32_t)(e0 + j - seg_desc[lo * 4]);
+            const uint32_t lo16 = raae::mask_keep(g, e) ? 0x3F80u : 0u, hi16 = raae::mask_keep(g, e + 1u) ? 0x3F80u : 0u;
+            o[j] = __uint_as_float(lo16 | (hi16 << 16));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (e0 + j < send && e0 + j < total) tape[e0 + j] = o[j];
+}
+
 __global__ __launch_bounds__(256) void rng_fill_kernel(float* tape, const int* seg_desc, const float* seg_scale, int nseg,
                                                        long total, unsigned long long seed,
                                                        const unsigned long long* counter) {
     const unsigned long long ctr = counter ? counter[0] : 0ull;
-    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q * 4 < total; q += (long)gridDim.x * 256) {
-        const long e0 = q * 4;
-        int lo = 0, hi = nseg - 1;
-        while (lo < hi) {                       // last segment whose offset <= e0
-            const int mid = (lo + hi + 1) >> 1;
-            if ((long)seg_desc[mid * 4] <= e0) lo = mid; else hi = mid - 1;
-        }
-        const int kind = seg_desc[lo * 4 + 2];
-        const long send = (long)seg_desc[lo * 4] + seg_desc[lo * 4 + 1];
-        float o[4];
-        if (kind == 0) {
-            // Philox counter = (position of these four floats in the numbering of the step's Gaussian elements) / 4
-            const long qg = ((long)seg_desc[lo * 4 + 3] + (e0 - seg_desc[lo * 4])) >> 2;
-            uint32_t c[4] = {(uint32_t)qg, (uint32_t)(qg >> 32), (uint32_t)ctr, (uint32_t)(ctr >> 32)};
-            philox(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-            const float r0 = sqrtf(-2.f * logf(u01(c[0]))), r1 = sqrtf(-2.f * logf(u01(c[2])));
-            const float a0 = 6.283185307179586f * u01(c[1]), a1 = 6.283185307179586f * u01(c[3]);
-            o[0] = r0 * cosf(a0); o[1] = r0 * sinf(a0); o[2] = r1 * cosf(a1); o[3] = r1 * sinf(a1);
-        } else if (kind == 1) {
-            // dropout multipliers {0, 1/keep}: the counter-based hash of raae_common.h on the element's tape index --
-            // the function a kernel with a raae_maskgen_t evaluates for a slot it generates itself
-            // (hash index = the slot's position in the numbering of ALL dropout elements of the step, seg_desc[.][3],
-            // + the element's index in the slot: the same whether the slot lives on the tape or in its consumer)
-            const raae::MaskGen g = raae::mask_gen_make(seed, ctr, (uint32_t)seg_desc[lo * 4 + 3], seg_scale[lo]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = raae::mask_val(g, (uint32_t)(e0 + j - seg_desc[lo * 4]));
-        } else {
-            // kind 2 (`precision: bf16`): keep flags {0, 1} stored as bf16 -- this thread's four floats hold eight of
-            // them (bf16 element i of the slot is hashed at index i of the slot); the dense kernels multiply by the fp32
-            // 1/keep
-            const raae::MaskGen g = raae::mask_gen_make(seed, ctr, (uint32_t)seg_desc[lo * 4 + 3], seg_scale[lo]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t e = 2u * (uint32_t)(e0 + j - seg_desc[lo * 4]);
-                const uint32_t lo16 = raae::mask_keep(g, e) ? 0x3F80u : 0u, hi16 = raae::mask_keep(g, e + 1u) ? 0x3F80u : 0u;
-                o[j] = __uint_as_float(lo16 | (hi16 << 16));
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q * 4 < total; q += (long)gridDim.x * 256)
+        fill_quad(tape, seg_desc, seg_scale, nseg, total, seed, ctr, q);
+}
+
+// ---- the head of a training step in ONE launch (was: tick, tape fill, batch gather -- 19 us at 256 rows) ----
+// Every workgroup reads the step counter and the row cursor AS THE PREVIOUS STEP LEFT THEM and works with counter + 1
+// and cursor + stride; the last workgroup to finish (ticket) stores the advanced values, and the Adam step counts, for
+// the kernels that follow.  Work: (a) gather the batch rows perm[cursor - B, cursor) (+ spectral noise: N(0, 1) from
+// the Philox block of the element's position in the step's Gaussian numbering, or from the tape in parity mode),
+// (b) fill the resident slots of the random tape.
+struct StepBeginArgs {
+    int* steps; int nsteps; unsigned step_mask; unsigned long long* rng_state; int* cursor; int stride; unsigned* ticket;
+    const float* spec; const float* aux; const long* idx; int B; int L; int n_aux; float spec_noise;
+    const float* noise_tape;      // parity mode: the noise slot on the (host-filled) tape; NULL: generated here
+    long noise_goff;              // position of the noise slot in the Gaussian numbering (multiple of 4)
+    float* spec_out; float* aux_out;
+    float* tape; const int* seg_desc; const float* seg_scale; int nseg; long total;     // nseg == 0: no fill
+};
+__global__ __launch_bounds__(256) void step_begin_kernel(StepBeginArgs a) {
+    const unsigned long long ctr = a.rng_state[0] + 1ull, seed = a.rng_state[1];
+    const int cur = a.cursor[0] + a.stride;
+    const long* idx = a.idx + (cur - a.B);
+    const long nthreads = (long)gridDim.x * 256, t0 = (long)blockIdx.x * 256 + threadIdx.x;
+    const long n = (long)a.B * a.L;
+    if ((a.L & 3) == 0) {
+        for (long i4 = t0; i4 * 4 < n; i4 += nthreads) {
+            const long i = i4 * 4;
+            const int b = (int)(i / a.L), l = (int)(i - (long)b * a.L);
+            float4 v = *reinterpret_cast<const float4*>(a.spec + (size_t)idx[b] * a.L + l);
+            if (a.spec_noise != 0.f) {
+                float z[4];
+                if (a.noise_tape != nullptr) { const float4 t = *reinterpret_cast<const float4*>(a.noise_tape + i); z[0] = t.x; z[1] = t.y; z[2] = t.z; z[3] = t.w; }
+                else normal4((a.noise_goff + i) >> 2, ctr, seed, z);
+                v.x += z[0] * a.spec_noise; v.y += z[1] * a.spec_noise; v.z += z[2] * a.spec_noise; v.w += z[3] * a.spec_noise;
             }
+            *reinterpret_cast<float4*>(a.spec_out + i) = v;
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (e0 + j < send && e0 + j < total) tape[e0 + j] = o[j];
+    } else {
+        for (long i = t0; i < n; i += nthreads) {
+            const int b = (int)(i / a.L), l = (int)(i - (long)b * a.L);
+            float v = a.spec[(size_t)idx[b] * a.L + l];
+            if (a.spec_noise != 0.f) {
+                if (a.noise_tape != nullptr) v += a.noise_tape[i] * a.spec_noise;
+                else { float z[4]; normal4((a.noise_goff + i) >> 2, ctr, seed, z); v += z[(a.noise_goff + i) & 3] * a.spec_noise; }
+            }
+            a.spec_out[i] = v;
+        }
+    }
+    const long na = (long)a.B * a.n_aux;
+    for (long i = t0; i < na; i += nthreads) {
+        const int b = (int)(i / a.n_aux), k = (int)(i - (long)b * a.n_aux);
+        a.aux_out[i] = a.aux[(size_t)idx[b] * a.n_aux + k];
+    }
+    if (a.nseg > 0)
+        for (long q = t0; q * 4 < a.total; q += nthreads)
+            fill_quad(a.tape, a.seg_desc, a.seg_scale, a.nseg, a.total, seed, ctr, q);
+    // the last workgroup publishes the advanced counters (nobody in THIS launch reads them again)
+    __shared__ unsigned s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = atomicAdd(a.ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_last && threadIdx.x == 0) {
+        for (int i = 0; i < a.nsteps; ++i) if (a.step_mask & (1u << i)) a.steps[i] += 1;
+        a.rng_state[0] = ctr;
+        a.cursor[0] = cur;
+        *a.ticket = 0u;
     }
 }
 
@@ -221,6 +296,26 @@ extern "C" int raae_rng_fill(float* tape, const int* seg_desc, const float* seg_
     if (g < 1) g = 1;
     hipLaunchKernelGGL(rng_fill_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, tape, seg_desc, seg_scale, nseg,
                        total, seed, counter);
+    RAAE_LAUNCH_RET();
+}
+
+extern "C" int raae_step_begin(const raae_step_begin_t* p, void* stream) {
+    RAAE_CHECK_ARG(p && p->steps && p->nsteps >= 0 && p->nsteps <= 32 && p->rng_state && p->cursor && p->ticket);
+    RAAE_CHECK_ARG(p->spec && p->aux && p->idx && p->spec_out && p->aux_out && p->B > 0 && p->L > 0 && p->n_aux > 0);
+    RAAE_CHECK_ARG(p->nseg == 0 || (p->tape && p->seg_desc && p->seg_scale && p->total > 0));
+    RAAE_CHECK_ARG((p->noise_goff & 3) == 0 && p->noise_goff >= 0);
+    StepBeginArgs a;
+    a.steps = p->steps; a.nsteps = p->nsteps; a.step_mask = p->step_mask; a.rng_state = p->rng_state; a.cursor = p->cursor;
+    a.stride = p->stride; a.ticket = p->ticket; a.spec = p->spec; a.aux = p->aux; a.idx = p->idx; a.B = p->B; a.L = p->L;
+    a.n_aux = p->n_aux; a.spec_noise = p->spec_noise; a.noise_tape = p->noise_tape; a.noise_goff = p->noise_goff;
+    a.spec_out = p->spec_out; a.aux_out = p->aux_out; a.tape = p->tape; a.seg_desc = p->seg_desc; a.seg_scale = p->seg_scale;
+    a.nseg = p->nseg; a.total = p->nseg > 0 ? p->total : 0;
+    long work = (long)p->B * p->L / 4;
+    if (a.total / 4 > work) work = a.total / 4;
+    long g = (work + 255) / 256;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(step_begin_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, a);
     RAAE_LAUNCH_RET();
 }
 

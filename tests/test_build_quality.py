@@ -7,12 +7,13 @@ from concurrent.futures import ThreadPoolExecutor
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rankaae_amd", "csrc")
-# kernels allowed to touch scratch memory: spilled registers in instances the reference's networks never launch
-# (the unsplit widest dense backward tile -- K > 256 behind an input transform, or N > 64 with K > 64: the 256- and
-# 512-point first layers run as 128-column slices, instance <8, 2, 16>, without scratch; three spilled registers in the
-# bf16 variant of the 512-column last layer); the masked variants of the large-batch conv, whose mask registers push
-# them over the 128-VGPR budget of four waves per SIMD
-ALLOW = {r"dense_bwd_kernelILi32ELi8E": 512, r"dense_bwd_kernelILi32ELi1ELi0ELb1E": 16, r"conv_fwd_strip_kernelI.*Lb1E": 32}
+# kernels allowed to touch scratch memory: a few spilled registers in instances the bench workloads never
+# launch (the unsplit widest dense backward tile -- the 256- and 512-point first layers run as 128-column slices,
+# instance <8, 2>; the masked variants of the large-batch conv, whose mask registers push them over the 128-VGPR budget
+# of four waves per SIMD).  dense_fwd2_kernel<64, 4>: two by-value argument blocks overflow the scalar registers; the
+# compiler reserves a 20-byte frame for the SGPR spill bookkeeping but the ISA holds no scratch instruction (checked
+# with -save-temps).
+ALLOW = {r"dense_fwd2_kernelILi64ELi4E": 32, r"dense_bwd_kernelILi32ELi8E": 64, r"conv_fwd_strip_kernelI.*Lb1E": 32}
 
 
 def _usage(src):

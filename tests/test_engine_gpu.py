@@ -91,6 +91,11 @@ INLINE_CASES = {
 # arbiter, tensors that may need the kink-adjusted arbiter, near-zero PReLU inputs it may account for.
 P2_CEILINGS = {
     "default": dict(arbiter_frac=0.05, arbiter_min=2, kink=2, kink_entries=16),
+    # measured (round 3, MI355X): fc_b4096 8 of 106 tensors through the float64 arbiter (the cancelling gradients of the
+    # adversarial and smoothness phases at 4096 rows), fc_example step 1: 11 through the arbiter, 2 of them through the
+    # kink-adjusted one over 5 near-zero PReLU inputs (1024 rows x 64 units x 8 layers); headroom of ~50 %
+    "fc_b4096": dict(arbiter_frac=0.0, arbiter_min=12, kink=2, kink_entries=16),
+    "fc_example": dict(arbiter_frac=0.0, arbiter_min=16, kink=4, kink_entries=16),
 }
 
 
@@ -554,7 +559,7 @@ def test_graph_replay_is_bitwise_eager(case):
 
 
 @pytest.mark.parametrize("case,over", [("fc_small", {}), ("fc_example", {}), ("compact_small", {}),
-                                       ("fc_b4096", {"n_steps": 2})])
+                                       ("fc_b4096", {"n_steps": 3})])
 def test_inline_masks_equal_tape_masks(case, over):
     """in ``rng_mode: philox`` the kernels that apply dropout regenerate their multipliers from a
     counter-based hash keyed by (seed, step, element) instead of reading a fp32 tape (``inline_masks``, default on).
@@ -568,8 +573,11 @@ def test_inline_masks_equal_tape_masks(case, over):
         eng = build_engine(dict(cfg, inline_masks=inline), 4321, spec, aux, use_graph=True, rng_mode="philox")
         assert eng.inline_masks == inline
         n_train = len(eng.train_spec)
-        eng.set_epoch(torch.randperm(n_train, generator=torch.Generator().manual_seed(3)), 0.25)
+        perm = torch.randperm(n_train, generator=torch.Generator().manual_seed(3))
+        eng.set_epoch(perm, 0.25)
         for _ in range(over.get("n_steps", 4)):
+            if eng._host_cursor + bs > n_train:           # (the 4096-row case has one batch per epoch)
+                eng.set_epoch(perm, 0.25)
             eng.step(bs)
         torch.cuda.synchronize()
         P = eng.plan(bs)
