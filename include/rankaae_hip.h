@@ -39,14 +39,16 @@ typedef struct {
 } raae_bn_t;
 
 /* Dropout multipliers generated inside the consuming kernel (rng_mode "philox", no tape read): element e of the slot is
- * kept iff hash(e + offset; seed, step) < keep * 2^32 and then scales by 1/keep -- the same function raae_rng_fill
- * evaluates for tape-resident slots, so both forms of a slot are bit-identical (nn.Dropout of the reference draws from
- * the global CPU generator instead: sc/clustering/model.py:337,351,360,526,545; parity mode keeps the host tape).
- * state == NULL: disabled (the consumer reads its `mask` tensor, or applies none). */
+ * kept iff hash(e + offset; k1, k2) < thr and then scales by inv = 1/keep -- the same function raae_rng_fill evaluates
+ * for tape-resident slots, so both forms of a slot are bit-identical (nn.Dropout of the reference draws from the global
+ * CPU generator instead: sc/clustering/model.py:337,351,360,526,545; parity mode keeps the host tape).  (k1, k2) are
+ * the step's hash keys, a function of (seed, step counter) that raae_step_begin / raae_step_tick store next to the
+ * counter once per step.  keys == NULL: disabled (the consumer reads its `mask` tensor, or applies none). */
 typedef struct {
-    const unsigned long long* state;   /* device: [0] step counter (raae_step_tick / raae_step_begin), [1] seed */
+    const unsigned* keys;              /* device: {k1, k2} of the current step (engine: rng_state + 2 words of 8 bytes) */
     unsigned offset;                   /* position of the slot's element 0 in the numbering of all dropout elements of a step */
-    float keep;                        /* 1 - p */
+    unsigned thr;                      /* min(2^32 - 1, (double)(float)keep * 2^32) */
+    float inv;                         /* 1.f / (float)keep */
 } raae_maskgen_t;
 
 /* ---- input transform applied while loading a dense layer's input ---- */
@@ -83,7 +85,7 @@ typedef struct {
     int storage;          /* RAAE_ST_* bits: which tensors are stored as bf16 (0: all fp32) */
     float mask_scale;     /* RAAE_ST_MASK: the bf16 mask holds {0, 1} and is multiplied by this fp32 1/(1-p) (a bf16
                              1/(1-p) would bias every activation by -0.16 %); 0 is read as 1 */
-    raae_maskgen_t gen;   /* gen.state != NULL: dropout multipliers generated in the kernel, `mask` must be NULL */
+    raae_maskgen_t gen;   /* gen.keys != NULL: dropout multipliers generated in the kernel, `mask` must be NULL */
 } raae_dense_fwd_t;
 int raae_dense_fwd2(const raae_dense_fwd_t* p, const raae_dense_fwd_t* q, int* nparts_p, int* nparts_q, void* stream);
 
@@ -435,7 +437,9 @@ int raae_block_bwd_b_wgrad(const raae_block_bwd_b_t* b, const raae_block_wgrad_t
 int raae_slab_reduce(const float* g_slabs, long slab_stride, const unsigned short* seg_nslab, long n, float* out,
                      int max_nslab, void* stream);
 /* once per training step: steps[i] += 1 for every bit i set in mask; rng_counter[0] += 1;
- * cursor[0] += cursor_inc (epoch row cursor of raae_gather_batch) */
+ * cursor[0] += cursor_inc (epoch row cursor of raae_gather_batch).  rng_counter points at the engine's
+ * {counter, seed, keys} words (three 8-byte words; may be NULL): the step's dropout hash keys (raae_maskgen_t.keys)
+ * are stored at rng_counter + 2. */
 int raae_step_tick(int* steps, int n, unsigned mask, unsigned long long* rng_counter, int* cursor, int cursor_inc,
                    void* stream);
 
@@ -449,7 +453,7 @@ int raae_rng_fill(float* tape, const int* seg_desc, const float* seg_scale, int 
                   unsigned long long seed, const unsigned long long* counter, void* stream);
 
 /* The head of a training step in one launch: raae_step_tick + raae_rng_fill + raae_gather_batch (trainer.py:106-113: the
- * DataLoader's next batch, ``spec_in += randn_like(spec_in) * spec_noise``).  rng_state (device) = {step counter, seed};
+ * DataLoader's next batch, ``spec_in += randn_like(spec_in) * spec_noise``).  rng_state (device) = {step counter, seed, hash keys};
  * the launch works with counter + 1 and cursor + stride and its last workgroup stores them (and steps[i] += 1 for the
  * bits of step_mask) for the kernels that follow.  noise_tape: the noise slot of a host-filled tape (parity mode) or
  * NULL: N(0, 1) generated in the kernel at position noise_goff of the step's Gaussian numbering -- bit for bit what
@@ -475,7 +479,7 @@ int raae_event_destroy(void* ev);
 int raae_stream_sync(void* stream);
 const char* raae_error_string(int code);
 int raae_device_info(int* cu_count, int* lds_bytes, char* name, int name_len);
-#define RAAE_ABI_VERSION 12
+#define RAAE_ABI_VERSION 13
 int raae_abi_version(void);
 /* First 16 hex digits of sha256 over include/rankaae_hip.h + csrc/raae_*.{h,inc,hip} at build time
  * (build.sh); the Python loader recomputes it and refuses a library built from other sources. */

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librankaae_hip.so")
 
 RAAE_MAX_PARTS = 512
-ABI_VERSION = 12
+ABI_VERSION = 13
 IN_NONE, IN_PRELU_BN_DROP, IN_PRELU_DROP = 0, 1, 2
 OUT_RAW, OUT_STATS_PRELU, OUT_STATS_RAW, OUT_SOFTPLUS, OUT_RELU = 0, 1, 2, 3, 4
 G_DIRECT, G_SOFTPLUS, G_PRELU_BN, G_PRELU, G_RELU = 0, 1, 2, 3, 4
@@ -24,7 +24,7 @@ class BnT(C.Structure):
 
 class MaskGenT(C.Structure):
     """``raae_maskgen_t``"""
-    _fields_ = [("state", C.c_void_p), ("offset", C.c_uint), ("keep", C.c_float)]
+    _fields_ = [("keys", C.c_void_p), ("offset", C.c_uint), ("thr", C.c_uint), ("inv", C.c_float)]
 
 
 class DenseFwdT(C.Structure):
@@ -47,6 +47,16 @@ class DenseBwdT(C.Structure):
 
 
 ST_X, ST_MASK, ST_Z = 1, 2, 4        # RAAE_ST_*: bf16 storage bits of the dense kernels
+
+
+class StepBeginT(C.Structure):
+    """``raae_step_begin_t``"""
+    _fields_ = [("steps", C.c_void_p), ("nsteps", C.c_int), ("step_mask", C.c_uint), ("rng_state", C.c_void_p),
+                ("cursor", C.c_void_p), ("stride", C.c_int), ("ticket", C.c_void_p), ("spec", C.c_void_p),
+                ("aux", C.c_void_p), ("idx", C.c_void_p), ("B", C.c_int), ("L", C.c_int), ("n_aux", C.c_int),
+                ("spec_noise", C.c_float), ("noise_tape", C.c_void_p), ("noise_goff", C.c_long),
+                ("spec_out", C.c_void_p), ("aux_out", C.c_void_p), ("tape", C.c_void_p), ("seg_desc", C.c_void_p),
+                ("seg_scale", C.c_void_p), ("nseg", C.c_int), ("total", C.c_long)]
 
 
 class DiscFusedT(C.Structure):
@@ -200,6 +210,7 @@ SIGNATURES = {
     "raae_block_bwd_b_wgrad": (_I, [C.POINTER(BlockBwdBT), C.POINTER(BlockWgradT), _PI, _PI, _P]),
     "raae_slab_reduce": (_I, [_P, _L, _P, _L, _P, _I, _P]),
     "raae_step_tick": (_I, [_P, _I, C.c_uint, _P, _P, _I, _P]),
+    "raae_step_begin": (_I, [C.POINTER(StepBeginT), _P]),
     "raae_rng_fill": (_I, [_P, _P, _P, _I, _L, C.c_ulonglong, _P, _P]),
     "raae_graph_begin": (_I, [_P]),
     "raae_graph_end": (_I, [_P, C.POINTER(C.c_void_p)]),

@@ -4,8 +4,13 @@ and log files as the reference's ``sc/cmd/train_sc.py:105-157`` (``training/job_
 losses.csv,final.pt}``, ``main_process_message.txt``), with the training itself on the MI355X HIP
 engine.  The ipyparallel engine farm (``train_sc.py:19-45``) becomes one worker process per visible GPU:
 trial ``k`` runs on worker ``k mod n`` and worker ``w`` uses GPU ``w mod ngpus`` (``RANKAAE_TRIAL_WORKERS``
-overrides ``n``; the config key ``trials_per_gpu`` puts several workers on each GPU, which scales to ~2.8x at 4 --
-DESIGN.md section 8).  When launched under
+overrides ``n``).  Several trials share a GPU (config key ``trials_per_gpu``, default 4 when ``trials > 1``): a 256-row
+step is one serial chain of ~10 us kernels that leaves most of the chip idle, and the chains of independent trials
+overlap on it.  ``trial_mode: threads`` (default): the trials of a worker run in threads of ONE process -- one engine,
+HIP stream and captured graph per trial, all of them feeding the same device; every trial draws from its own host
+generator (seeded ``trial_seed + k``; ``trial_seed`` defaults to a draw from the global generator), so a trial's result
+does not depend on what runs beside it (tests/test_trainer_gpu.py).  ``trial_mode: processes``: one worker process per
+concurrent trial, as in round 2.  When launched under
 ``torch.distributed.run`` (WORLD_SIZE > 1) every trial instead trains data-parallel over RCCL: all ranks run the trials
 one after the other, each trial is ONE training run (``Trainer`` shards every global batch over the ranks and averages
 the gradients, rankaae_amd/trainer.py), and rank 0 alone writes the logs, checkpoints and ``final.pt``."""
@@ -13,7 +18,9 @@ import argparse
 import logging
 import os
 import signal
+import threading
 import time
+
 
 import numpy as np
 import torch
@@ -28,7 +35,9 @@ def timeout_handler(signum, frame):
 
 
 def run_training(job_number, work_dir, train_config, verbose, data_file, timeout_hours=0,
-                 logger=logging.getLogger("training")):
+                 logger=logging.getLogger("training"), host_rng=None, init_lock=None):
+    """``host_rng`` / ``init_lock``: thread mode (several trials in this process) -- the trial's own host generator, and
+    the lock under which the global generator is seeded for the construction of ITS networks."""
     work_dir = f"{work_dir}/training/job_{job_number + 1}"
     os.makedirs(work_dir, exist_ok=True)
     if _is_lead_rank():
@@ -41,9 +50,33 @@ def run_training(job_number, work_dir, train_config, verbose, data_file, timeout
     igpu = local_id % ngpus if ngpus > 0 else -1
     start = time.time()
     logger.info(f"Training started for trial {job_number + 1}.")
-    trainer = Trainer.from_data(data_file, igpu=igpu, verbose=verbose, work_dir=work_dir,
-                                config_parameters=train_config, logger=logger, loss_logger=loss_logger)
-    trainer.freeze_gc = bool(train_config.get("freeze_gc", True))   # a dedicated training process: collector held off
+    if host_rng is None:
+        trainer = Trainer.from_data(data_file, igpu=igpu, verbose=verbose, work_dir=work_dir,
+                                    config_parameters=train_config, logger=logger, loss_logger=loss_logger)
+    else:
+        with init_lock:      # nn.Module constructors draw their initial weights from the GLOBAL generator
+            torch.manual_seed(host_rng.initial_seed())
+            trainer = Trainer.from_data(data_file, igpu=igpu, verbose=verbose, work_dir=work_dir,
+                                        config_parameters=train_config, logger=logger, loss_logger=loss_logger,
+                                        host_rng=host_rng)
+    trainer.freeze_gc = bool(train_config.get("freeze_gc", host_rng is None))   # a dedicated training process: collector held off
+    timer = None
+    if host_rng is not None:
+        # a thread: no signals here.  A timer asks the trainer to stop; train() raises the reference's exception at the
+        # next epoch boundary
+        if timeout_hours > 0:
+            timer = threading.Timer(float(timeout_hours) * 3600.0, trainer.request_stop, args=("Training Overtime!",))
+            timer.daemon = True
+            timer.start()
+        try:
+            metrics = trainer.train()
+        finally:
+            if timer is not None:
+                timer.cancel()
+        logger.info(metrics)
+        time_used = time.time() - start
+        logger.info(f"Training finished. Time used: {time_used:.2f}s.\n\n")
+        return metrics, time_used
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         # data parallel: the rank whose alarm fires must not leave the others waiting in a collective -- it asks the
         # trainer to stop, and every rank raises the reference's exception together at the next epoch boundary
@@ -81,17 +114,60 @@ def assign_trials(trials, nworkers):
     return [list(range(w, trials, nworkers)) for w in range(nworkers)]
 
 
-def _trial_worker(worker, jobs, work_dir, config_dict, verbose, data_file, timeout):
+def _trial_worker(worker, jobs, work_dir, config_dict, verbose, data_file, timeout, threads=1, trial_seed=None):
     # a spawned process: nothing has touched the GPU yet; LOCAL_RANK picks it in run_training
     os.environ["LOCAL_RANK"] = str(worker)
     cfg = Parameters(config_dict)
-    return [(k,) + tuple(run_training(k, work_dir, cfg, verbose, data_file, timeout)) for k in jobs]
+    if threads <= 1:
+        return [(k,) + tuple(run_training(k, work_dir, cfg, verbose, data_file, timeout)) for k in jobs]
+    return run_trials_threaded(jobs, threads, work_dir, cfg, verbose, data_file, timeout, trial_seed)
+
+
+def run_trials_threaded(jobs, threads, work_dir, train_config, verbose, data_file, timeout, trial_seed):
+    """The trials ``jobs`` of this process, ``threads`` at a time, each in a thread with its own engine / stream / graph
+    and its own host generator (seed ``trial_seed + k``): ``[(k, metrics, time_used)]``."""
+    from concurrent.futures import ThreadPoolExecutor
+    if train_config.get("rng_mode", "philox") != "philox":
+        raise ValueError("trial_mode: threads needs rng_mode: philox (the parity mode draws every random number of "
+                         "every trial from the one global CPU generator: use trial_mode: processes)")
+    init_lock = threading.Lock()
+
+    def one(k):
+        g = torch.Generator()
+        g.manual_seed(int(trial_seed) + k)
+        return (k,) + tuple(run_training(k, work_dir, train_config, verbose, data_file, timeout, host_rng=g,
+                                         init_lock=init_lock))
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        return list(ex.map(one, jobs))
 
 
 def run_trials(trials, work_dir, train_config, verbose, data_file, timeout, logger):
     """All trials; returns ``[(metrics, time_used)]`` in trial order and the number of worker processes."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     nworkers = 1
+    mode = str(train_config.get("trial_mode", "threads"))
+    if mode not in ("threads", "processes"):
+        raise ValueError(f"trial_mode must be 'threads' or 'processes', not {mode!r}")
+    seeded = train_config.get("trial_seed", None) is not None
+    if world == 1 and (trials > 1 or seeded) and mode == "threads" and train_config.get("rng_mode", "philox") == "philox":
+        # one worker process per GPU; inside it `trials_per_gpu` trials at a time in threads
+        per_gpu = int(os.environ.get("RANKAAE_TRIALS_PER_GPU", train_config.get("trials_per_gpu", 4)))
+        ngpu = max(1, torch.cuda.device_count())
+        nproc = max(1, min(int(os.environ.get("RANKAAE_TRIAL_WORKERS", ngpu)), trials))
+        threads = max(1, min(per_gpu, -(-trials // nproc)))
+        seed = train_config.get("trial_seed", None)
+        if seed is None:
+            seed = int(torch.empty((), dtype=torch.int64).random_().item()) & 0x3fffffff
+        if nproc == 1:
+            done = sorted(run_trials_threaded(list(range(trials)), threads, work_dir, train_config, verbose, data_file,
+                                              timeout, seed))
+            return [(m, t) for _, m, t in done], threads
+        import multiprocessing as mp
+        with mp.get_context("spawn").Pool(nproc) as pool:
+            parts = pool.starmap(_trial_worker, [(w, jobs, work_dir, train_config.to_dict(), verbose, data_file, timeout,
+                                                  threads, seed) for w, jobs in enumerate(assign_trials(trials, nproc))])
+        done = sorted(r for part in parts for r in part)
+        return [(m, t) for _, m, t in done], nproc * threads
     if world == 1 and trials > 1:
         # device_count() does not initialise the GPU, so the workers can still be spawned after it
         # `trials_per_gpu` (config key, or RANKAAE_TRIALS_PER_GPU): worker processes that share one GPU.  At batches

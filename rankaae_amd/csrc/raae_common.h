@@ -322,9 +322,17 @@ __device__ __forceinline__ MaskGen mask_gen_make(unsigned long long seed, unsign
     m.off = off;
     return m;
 }
-// state (device): [0] = step counter (advanced once per step), [1] = seed
+// the step's keys as raae_step_begin / raae_step_tick stored them (two words: no hashing, no counter arithmetic here)
 __device__ __forceinline__ MaskGen mask_gen_from(const raae_maskgen_t& g) {
-    return mask_gen_make(g.state[1], g.state[0], g.offset, g.keep);
+    MaskGen m;
+    m.k1 = g.keys[0]; m.k2 = g.keys[1]; m.thr = g.thr; m.off = g.offset; m.inv = g.inv;
+    return m;
+}
+// ... and what stores them: words [2] of the {counter, seed, keys} state
+__device__ __forceinline__ void mask_keys_store(unsigned long long* state, unsigned long long seed, unsigned long long ctr) {
+    const MaskGen m = mask_gen_make(seed, ctr, 0u, 1.f);
+    reinterpret_cast<unsigned*>(state + 2)[0] = m.k1;
+    reinterpret_cast<unsigned*>(state + 2)[1] = m.k2;
 }
 __device__ __forceinline__ bool mask_keep(const MaskGen& m, uint32_t e) {     // e: element index inside the slot
     return lowbias32(lowbias32(e + m.off + m.k1) ^ m.k2) < m.thr;

@@ -74,11 +74,8 @@ __device__ __forceinline__ float in_transform(float v, int k, int in_kind, const
 // hash generator (raae_common.h), or nowhere.
 struct MaskSrc {
     const float* ptr; bool bf; float scale; bool gen; raae::MaskGen g;
-    unsigned long long seed, ctr; unsigned off; float keep;      // generator: raw state, requested early (arm), keyed late (key)
     __device__ __forceinline__ bool any() const { return gen || ptr != nullptr; }
-    // the generator's keys from the state words requested by mask_src(): called where the multipliers are first needed,
-    // BEHIND the statistic prologue -- deriving them at once would put the state's round trip in front of every other load
-    __device__ __forceinline__ void key() { if (gen) g = raae::mask_gen_make(seed, ctr, off, keep); }
+    __device__ __forceinline__ void key() {}
     __device__ __forceinline__ float4 at4(size_t o) const {        // o a multiple of 4
         if (gen) return raae::mask_val4(g, (uint32_t)o);
         if (bf) { const float4 m = bf16x4_at(ptr, o); return make_float4(m.x * scale, m.y * scale, m.z * scale, m.w * scale); }
@@ -94,9 +91,8 @@ __device__ __forceinline__ MaskSrc mask_src(const float* mask, int in_kind, int 
     m.ptr = in_kind != RAAE_IN_NONE ? mask : nullptr;
     m.bf = (storage & RAAE_ST_MASK) != 0;
     m.scale = scale != 0.f ? scale : 1.f;
-    m.gen = in_kind != RAAE_IN_NONE && gen.state != nullptr;
-    m.seed = 0ull; m.ctr = 0ull; m.off = gen.offset; m.keep = gen.keep;
-    if (m.gen) { m.ctr = gen.state[0]; m.seed = gen.state[1]; }
+    m.gen = in_kind != RAAE_IN_NONE && gen.keys != nullptr;
+    if (m.gen) m.g = raae::mask_gen_from(gen);         // two words; first used behind the statistic prologue
     return m;
 }
 
@@ -697,7 +693,7 @@ static int prep_dense_fwd(const float* x, int B, int K, int in_kind, const float
     a.out_partials = out_partials;
     a.storage = 0;
     a.mask_scale = 1.f;
-    a.gen.state = nullptr; a.gen.offset = 0; a.gen.keep = 1.f;
+    a.gen.keys = nullptr; a.gen.offset = 0; a.gen.thr = 0xFFFFFFFFu; a.gen.inv = 1.f;
     const int K4 = (K + 3) & ~3;
     RAAE_CHECK_ARG(K4 <= 512 && (in_kind != RAAE_IN_PRELU_BN_DROP || K <= 256));
     a.pitch = K4 + 2;
@@ -754,7 +750,7 @@ extern "C" int raae_dense_fwd_s(const raae_dense_fwd_t* p, int* out_nparts, void
     const int rc = prep_dense_fwd(p->x, p->B, p->K, p->in_kind, p->slope, p->has_bn ? &p->bn : nullptr, p->mask, p->w,
                                   p->bias, p->N, p->z, p->out_kind, p->out_slope, p->out_partials, a, grid, lds, kq);
     if (rc) return rc;
-    RAAE_CHECK_ARG(!(p->gen.state && p->mask) && !(p->gen.state && !(p->gen.keep > 0.f)));
+    RAAE_CHECK_ARG(!(p->gen.keys && p->mask) && !(p->gen.keys && !(p->gen.inv >= 1.f)));
     a.storage = p->storage; a.mask_scale = p->mask_scale; a.gen = p->gen;
     if (out_nparts) *out_nparts = (int)grid.x;
     launch_dense_fwd(a, grid, lds, kq, (hipStream_t)stream);
@@ -774,7 +770,7 @@ extern "C" int raae_dense_fwd2(const raae_dense_fwd_t* p, const raae_dense_fwd_t
     rc = prep_dense_fwd(q->x, q->B, q->K, q->in_kind, q->slope, q->has_bn ? &q->bn : nullptr, q->mask, q->w, q->bias,
                         q->N, q->z, q->out_kind, q->out_slope, q->out_partials, k.y, g2, l2, q2, false);
     if (rc) return rc;
-    RAAE_CHECK_ARG(!(p->gen.state && p->mask) && !(q->gen.state && q->mask));
+    RAAE_CHECK_ARG(!(p->gen.keys && p->mask) && !(q->gen.keys && q->mask));
     k.x.storage = p->storage; k.y.storage = q->storage;
     k.x.mask_scale = p->mask_scale; k.y.mask_scale = q->mask_scale;
     k.x.gen = p->gen; k.y.gen = q->gen;
@@ -838,7 +834,7 @@ extern "C" int raae_dense_bwd_s(const raae_dense_bwd_t* p, int* nslab, void* str
     RAAE_CHECK_ARG(in_kind == RAAE_IN_NONE || p->slope);
     RAAE_CHECK_ARG(in_kind != RAAE_IN_PRELU_BN_DROP || bn);
     RAAE_CHECK_ARG(!(p->dx && in_kind == RAAE_IN_PRELU_BN_DROP) || p->dx_partials);
-    RAAE_CHECK_ARG(!(p->gen.state && p->mask) && !(p->gen.state && !(p->gen.keep > 0.f)));
+    RAAE_CHECK_ARG(!(p->gen.keys && p->mask) && !(p->gen.keys && !(p->gen.inv >= 1.f)));
     DenseBwdArgs a;
     a.g = p->g; a.g_kind = g_kind; a.g_partials = p->g_partials; a.g_nparts = p->g_nparts; a.zout = p->zout;
     a.out_slope = p->out_slope;

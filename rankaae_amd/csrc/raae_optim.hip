@@ -117,7 +117,10 @@ __global__ void tick_kernel(int* steps, int n, unsigned mask, unsigned long long
                             int cursor_inc) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         for (int i = 0; i < n; ++i) if (mask & (1u << i)) steps[i] += 1;
-        if (rng_counter) rng_counter[0] += 1ull;
+        if (rng_counter) {
+            rng_counter[0] += 1ull;
+            raae::mask_keys_store(rng_counter, rng_counter[1], rng_counter[0]);       // {counter, seed, keys}
+        }
         if (cursor) cursor[0] += cursor_inc;
     }
 }
@@ -208,8 +211,24 @@ struct StepBeginArgs {
     float* tape; const int* seg_desc; const float* seg_scale; int nseg; long total;     // nseg == 0: no fill
 };
 __global__ __launch_bounds__(256) void step_begin_kernel(StepBeginArgs a) {
-    const unsigned long long ctr = a.rng_state[0] + 1ull, seed = a.rng_state[1];
-    const int cur = a.cursor[0] + a.stride;
+    // Thread 0 reads the old counters, hands them to the workgroup through LDS and only then takes the workgroup's
+    // ticket -- at the START (the value comes back while the workgroup works): whoever draws the last one knows that
+    // every workgroup has READ the counters (the LDS stores need the loaded values, and precede the ticket in program
+    // order) and publishes the advanced ones at its end.  (Tickets of one address serialise at ~40 ns each: 2048
+    // workgroups taking them at their END made this kernel 84 us long; the grid is now 64 ... 512 workgroups.)
+    __shared__ unsigned long long s_ctr, s_seed;
+    __shared__ int s_cur;
+    unsigned my_ticket = 0u;
+    if (threadIdx.x == 0) {
+        s_ctr = a.rng_state[0] + 1ull;
+        s_seed = a.rng_state[1];
+        s_cur = a.cursor[0] + a.stride;
+        __threadfence();
+        my_ticket = atomicAdd(a.ticket, 1u);
+    }
+    __syncthreads();
+    const unsigned long long ctr = s_ctr, seed = s_seed;
+    const int cur = s_cur;
     const long* idx = a.idx + (cur - a.B);
     const long nthreads = (long)gridDim.x * 256, t0 = (long)blockIdx.x * 256 + threadIdx.x;
     const long n = (long)a.B * a.L;
@@ -242,20 +261,27 @@ __global__ __launch_bounds__(256) void step_begin_kernel(StepBeginArgs a) {
         const int b = (int)(i / a.n_aux), k = (int)(i - (long)b * a.n_aux);
         a.aux_out[i] = a.aux[(size_t)idx[b] * a.n_aux + k];
     }
-    if (a.nseg > 0)
+    if (a.nseg > 0) {
+        // the segment table goes to LDS once per workgroup: the binary search of every quad is then six LDS reads, not
+        // six dependent global round trips (a thread fills ~16 quads here, not one as in rng_fill_kernel)
+        __shared__ int s_desc[4 * 256];
+        __shared__ float s_scale[256];
+        const int* desc = a.seg_desc;
+        const float* scale = a.seg_scale;
+        if (a.nseg <= 256) {
+            for (int i = threadIdx.x; i < 4 * a.nseg; i += 256) s_desc[i] = a.seg_desc[i];
+            for (int i = threadIdx.x; i < a.nseg; i += 256) s_scale[i] = a.seg_scale[i];
+            __syncthreads();
+            desc = s_desc; scale = s_scale;
+        }
         for (long q = t0; q * 4 < a.total; q += nthreads)
-            fill_quad(a.tape, a.seg_desc, a.seg_scale, a.nseg, a.total, seed, ctr, q);
-    // the last workgroup publishes the advanced counters (nobody in THIS launch reads them again)
-    __shared__ unsigned s_last;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        s_last = atomicAdd(a.ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+            fill_quad(a.tape, desc, scale, a.nseg, a.total, seed, ctr, q);
     }
-    __syncthreads();
-    if (s_last && threadIdx.x == 0) {
+    // the workgroup that STARTED last publishes the advanced counters (nobody in this launch reads them again)
+    if (threadIdx.x == 0 && my_ticket == gridDim.x - 1) {
         for (int i = 0; i < a.nsteps; ++i) if (a.step_mask & (1u << i)) a.steps[i] += 1;
         a.rng_state[0] = ctr;
+        raae::mask_keys_store(a.rng_state, seed, ctr);
         a.cursor[0] = cur;
         *a.ticket = 0u;
     }
@@ -312,9 +338,9 @@ extern "C" int raae_step_begin(const raae_step_begin_t* p, void* stream) {
     a.nseg = p->nseg; a.total = p->nseg > 0 ? p->total : 0;
     long work = (long)p->B * p->L / 4;
     if (a.total / 4 > work) work = a.total / 4;
-    long g = (work + 255) / 256;
-    if (g > 2048) g = 2048;
-    if (g < 1) g = 1;
+    long g = (work + 4095) / 4096;          // ~16 quads per thread
+    if (g > 512) g = 512;
+    if (g < 64) g = 64;
     hipLaunchKernelGGL(step_begin_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, a);
     RAAE_LAUNCH_RET();
 }

@@ -24,8 +24,11 @@ class Loader:
     """Minimal stand-in for ``torch.utils.data.DataLoader``: what ``Trainer`` needs
     (``dataset``, ``batch_size``, ``len``) plus the reference's shuffle order."""
 
-    def __init__(self, dataset, batch_size, shuffle):
+    def __init__(self, dataset, batch_size, shuffle, generator=None):
         self.dataset, self.batch_size, self.shuffle = dataset, batch_size, shuffle
+        # None: the GLOBAL torch CPU generator, as the reference's DataLoader (one trial per process); a private
+        # generator when several trials share a process (train_sc's thread mode: each trial its own stream)
+        self.generator = generator
 
     def __len__(self):
         return -(-len(self.dataset) // self.batch_size)
@@ -33,10 +36,10 @@ class Loader:
     def epoch_permutation(self):
         """Row order of one epoch exactly as ``DataLoader(shuffle=True, num_workers=0)`` draws it
         (SURVEY.md finding 9): iterator ``_base_seed`` draw, sampler seed draw, private randperm."""
-        torch.empty((), dtype=torch.int64).random_()
+        torch.empty((), dtype=torch.int64).random_(generator=self.generator)
         if not self.shuffle:
             return torch.arange(len(self.dataset))
-        seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        seed = int(torch.empty((), dtype=torch.int64).random_(generator=self.generator).item())
         g = torch.Generator()
         g.manual_seed(seed)
         return torch.randperm(len(self.dataset), generator=g)
@@ -104,8 +107,8 @@ def load_csv(csv_fn, n_aux, cache=True):
     return spec, aux, grid, index
 
 
-def get_dataloaders(csv_fn, batch_size, train_val_test_ratios=(0.7, 0.15, 0.15), n_aux=0, arrays=None):
-    """``arrays=(spec, aux)`` bypasses the CSV (synthetic data already in memory)."""
+def get_dataloaders(csv_fn, batch_size, train_val_test_ratios=(0.7, 0.15, 0.15), n_aux=0, arrays=None, generator=None):
+    """``arrays=(spec, aux)`` bypasses the CSV (synthetic data already in memory); ``generator``: see ``Loader``."""
     if arrays is None:
         spec, aux, grid, index = load_csv(csv_fn, n_aux)
     else:
@@ -117,6 +120,6 @@ def get_dataloaders(csv_fn, batch_size, train_val_test_ratios=(0.7, 0.15, 0.15),
     for i, cnt in enumerate(n):
         ds = AuxSpectraDataset(spec[lo:lo + cnt], None if aux is None else aux[lo:lo + cnt], grid,
                                index[lo:lo + cnt], meta)
-        loaders.append(Loader(ds, batch_size, shuffle=(i == 0)))
+        loaders.append(Loader(ds, batch_size, shuffle=(i == 0), generator=generator))
         lo += cnt
     return loaders

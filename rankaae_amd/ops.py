@@ -54,12 +54,18 @@ def dense_fwd(x, B, K, in_kind, slope, bn, mask, w, bias, N, z, out_kind, out_sl
 
 
 def make_gen(gen):
-    """``raae_maskgen_t`` from ``(state tensor [counter, seed], slot offset, keep)`` or None (disabled)."""
+    """``raae_maskgen_t`` from ``(state tensor [counter, seed, keys], slot offset, keep)`` or None (disabled): the
+    step's hash keys live in the third 8-byte word of the engine's state; threshold and multiplier are formed here
+    exactly as ``raae_rng_fill`` forms them from the float keep probability."""
+    import numpy as np
     g = _lib.MaskGenT()
     if gen is not None:
         state, off, keep = gen
-        assert state.dtype == torch.int64 and state.is_cuda and 0 <= off < 2 ** 32 and 0.0 < keep <= 1.0
-        g.state, g.offset, g.keep = state.data_ptr(), int(off), float(keep)
+        assert state.dtype == torch.int64 and state.is_cuda and state.numel() >= 3 and 0 <= off < 2 ** 32 and 0.0 < keep <= 1.0
+        k32 = np.float32(keep)
+        g.keys, g.offset = state.data_ptr() + 16, int(off)
+        g.thr = min(0xFFFFFFFF, int(float(k32) * 4294967296.0))
+        g.inv = float(np.float32(1.0) / k32)
     return g
 
 
@@ -288,6 +294,23 @@ def step_tick(steps, n, mask, rng_counter, cursor, cursor_inc):
                                      _ptr(cursor, torch.int32), cursor_inc, _stream()), "raae_step_tick")
 
 
+def step_begin(steps, nsteps, mask, rng_state, cursor, stride, ticket, spec, aux, idx, B, L, n_aux, spec_noise, noise_tape,
+               noise_goff, spec_out, aux_out, tape=None):
+    """Tick + tape fill + batch gather in one launch (``raae_step_begin``).  ``noise_tape``: the noise slot of a
+    host-filled tape (parity mode) or None (generated in the kernel at position ``noise_goff`` of the Gaussian
+    numbering); ``tape``: an engine ``Tape`` whose resident slots are filled here (None / no slots: no fill)."""
+    a = _lib.StepBeginT()
+    a.steps, a.nsteps, a.step_mask, a.rng_state = _p(steps), int(nsteps), int(mask), _p(rng_state)
+    a.cursor, a.stride, a.ticket = _p(cursor), int(stride), _p(ticket)
+    a.spec, a.aux, a.idx, a.B, a.L, a.n_aux = _p(spec), _p(aux), _p(idx), B, L, n_aux
+    a.spec_noise, a.noise_tape, a.noise_goff = float(spec_noise), _p(noise_tape), int(noise_goff)
+    a.spec_out, a.aux_out = _p(spec_out), _p(aux_out)
+    if tape is not None and len(tape.segs) > 0:
+        a.tape, a.seg_desc, a.seg_scale, a.nseg, a.total = _p(tape.buf), _p(tape.seg_desc), _p(tape.seg_scale), len(tape.segs), tape.total
+    assert steps.dtype == torch.int32 and rng_state.dtype == torch.int64 and cursor.dtype == torch.int32 and idx.dtype == torch.int64
+    check(_lib.load().raae_step_begin(C.byref(a), _stream()), "raae_step_begin")
+
+
 def rng_fill(tape, seg_desc, seg_scale, nseg, total, seed, counter):
     check(_lib.load().raae_rng_fill(_ptr(tape), _ptr(seg_desc, torch.int32), _ptr(seg_scale), nseg, total,
                                     C.c_ulonglong(seed), _ptr(counter, torch.int64), _stream()), "raae_rng_fill")
@@ -296,17 +319,20 @@ def rng_fill(tape, seg_desc, seg_scale, nseg, total, seed, counter):
 class Graph:
     """A captured HIP graph of one training step (hipStreamBeginCapture / hipGraphLaunch)."""
 
-    active = 0      # captures in progress in this process (any engine): StepEngine.close() must not run inside one
+    active = 0      # captures in progress in this process (any engine, any thread): StepEngine.close() must not run inside one
+    _lock = __import__("threading").Lock()
 
     def __init__(self):
         self.handle = C.c_void_p()
 
     def begin(self):
         check(_lib.load().raae_graph_begin(_stream()), "raae_graph_begin")
-        Graph.active += 1
+        with Graph._lock:
+            Graph.active += 1
 
     def end(self):
-        Graph.active -= 1
+        with Graph._lock:
+            Graph.active -= 1
         check(_lib.load().raae_graph_end(_stream(), C.byref(self.handle)), "raae_graph_end")
 
     def launch(self):

@@ -88,7 +88,9 @@ class Trainer:
         self.world, self.rank, self.pg = self._data_parallel_setup(device)
         # one draw from the global generator per trial (also when `seed` is given, so that the generator's state
         # does not depend on the key): trials of one run then use different noise / dropout / latent streams
-        drawn = int(torch.empty((), dtype=torch.int64).random_().item()) & 0x7fffffff if cfg.get("rng_mode", "philox") == "philox" else 0
+        # (the training loader's generator: the global one unless the trial was given its own -- train_sc's thread mode)
+        host_rng = getattr(train_loader, "generator", None)
+        drawn = int(torch.empty((), dtype=torch.int64).random_(generator=host_rng).item()) & 0x7fffffff if cfg.get("rng_mode", "philox") == "philox" else 0
         seed = int(cfg.get("seed", drawn)) + self.rank
         self.engine = StepEngine(encoder, decoder, discriminator, cfg, device,
                                  rng_mode=cfg.get("rng_mode", "philox"), seed=seed,
@@ -234,6 +236,8 @@ class Trainer:
                 # a rank's timeout fired: all ranks leave here together (a rank raising on its own would leave the
                 # others waiting in the next step's all-reduce)
                 raise Exception(self._stop_reason or "Training Overtime!")
+            if self.world == 1 and self._stop_reason is not None:      # thread mode of train_sc: a timer asked for it
+                raise Exception(self._stop_reason)
             combined_metric = -(np.array(self.metric_weights) * np.array(metrics)).sum()
             if combined_metric > best_combined_metric:
                 best_combined_metric = combined_metric
@@ -253,11 +257,13 @@ class Trainer:
     @classmethod
     def from_data(cls, csv_fn, igpu=0, verbose=True, work_dir='.', train_ratio=0.7, validation_ratio=0.15,
                   test_ratio=0.15, config_parameters=Parameters({}), logger=logging.getLogger("from_data"),
-                  loss_logger=logging.getLogger("losses"), arrays=None):
+                  loss_logger=logging.getLogger("losses"), arrays=None, host_rng=None):
+        """``host_rng`` (build-only): a private ``torch.Generator`` for this trial's epoch permutations and device-RNG
+        seed instead of the global CPU generator (several trials in one process)."""
         p = config_parameters
         assert p.ae_form in AE_CLS_DICT
         dl_train, dl_val, _ = get_dataloaders(csv_fn, p.batch_size, (train_ratio, validation_ratio, test_ratio),
-                                              n_aux=p.n_aux, arrays=arrays)
+                                              n_aux=p.n_aux, arrays=arrays, generator=host_rng)
         if not torch.cuda.is_available():
             raise RuntimeError("rankaae_amd needs an MI355X GPU: the training path has no CPU fallback "
                                "(the reference would log 'Use Slow CPU!' here)")

@@ -565,13 +565,17 @@ def test_inline_masks_equal_tape_masks(case, over):
     counter-based hash keyed by (seed, step, element) instead of reading a fp32 tape (``inline_masks``, default on).
     ``raae_rng_fill`` evaluates the same function for slots that stay on the tape, and every slot keeps its position in
     the numbering whether it is resident or not: with ``inline_masks: false`` (everything on the tape) the run is BIT
-    FOR BIT the same -- weights, Adam moments, BatchNorm statistics, losses -- eagerly and as graph replay."""
+    FOR BIT the same -- weights, Adam moments, BatchNorm statistics, losses -- eagerly and as graph replay.  The same
+    holds for the fused head of the step (``raae_step_begin``: counters, tape fill, batch gather and in-kernel spectral
+    noise in one launch) against ``fused_step_begin: false`` (``raae_step_tick`` + ``raae_rng_fill`` +
+    ``raae_gather_batch`` with the noise on the tape), in every combination."""
     g, cfg, spec, aux = load_case(case)
     bs = cfg["batch_size"]
     out = []
-    for inline in (True, False):
-        eng = build_engine(dict(cfg, inline_masks=inline), 4321, spec, aux, use_graph=True, rng_mode="philox")
-        assert eng.inline_masks == inline
+    for inline, fused in ((True, True), (False, False), (True, False), (False, True)):
+        eng = build_engine(dict(cfg, inline_masks=inline, fused_step_begin=fused), 4321, spec, aux, use_graph=True,
+                           rng_mode="philox")
+        assert eng.inline_masks == inline and eng.fused_begin == fused
         n_train = len(eng.train_spec)
         perm = torch.randperm(n_train, generator=torch.Generator().manual_seed(3))
         eng.set_epoch(perm, 0.25)
@@ -583,11 +587,11 @@ def test_inline_masks_equal_tape_masks(case, over):
         P = eng.plan(bs)
         out.append(([eng.arena.P.clone()] + [b_.clone() for mod in (eng.enc_mod, eng.dec_mod) for b_ in mod.buffers()] +
                     [o.v.clone() for o in eng.opts.values()], eng.losses(), P.tape.total))
-    for a, b in zip(out[0][0], out[1][0]):
-        assert torch.equal(a, b), "in-kernel dropout multipliers differ from the tape's"
-    assert out[0][1] == out[1][1]
-    if cfg["ae_form"] == "FC":
-        assert out[0][2] < out[1][2], "the dense networks' multipliers should have left the tape"
+    for other in out[1:]:
+        for a, b in zip(out[0][0], other[0]):
+            assert torch.equal(a, b), "in-kernel dropout multipliers / noise differ from the tape's"
+        assert out[0][1] == other[1]
+    assert out[0][2] < out[1][2], "multipliers and spectral noise should have left the tape"
 
 
 def test_dropout_hash_statistics():

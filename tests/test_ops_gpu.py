@@ -281,7 +281,7 @@ def test_adam_matches_torch(decoupled, wd):
     p, m, v = dev(p0), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
     hyper = torch.tensor([0.01, 0.99, 0.9999, 1e-8, wd], dtype=torch.float64, device=DEV)
     step = torch.zeros(4, dtype=torch.int32, device=DEV)
-    rngc = torch.zeros(1, dtype=torch.int64, device=DEV)
+    rngc = torch.zeros(3, dtype=torch.int64, device=DEV)          # {step counter, seed, the step's dropout hash keys}
     cursor = torch.zeros(1, dtype=torch.int32, device=DEV)
     nslab = 3
     seg = torch.full((n // 64,), nslab, dtype=torch.int16, device=DEV)
@@ -294,7 +294,7 @@ def test_adam_matches_torch(decoupled, wd):
         ops.step_tick(step, 4, 0b0101, rngc, cursor, 256)
         ops.adam_step(p, m, v, dev(slabs), n, seg, n, hyper, step[2:], decoupled, max_nslab=(3 if it % 2 else 40))
     torch.cuda.synchronize()
-    assert step.tolist() == [5, 0, 5, 0] and int(rngc) == 5 and int(cursor) == 5 * 256
+    assert step.tolist() == [5, 0, 5, 0] and int(rngc[0]) == 5 and int(rngc[2]) != 0 and int(cursor) == 5 * 256
     pr = ref.detach().clone()
     pr[5 * 64:6 * 64] = p0[5 * 64:6 * 64]
     close(p, pr, 2e-6, 2e-7, "params after 5 steps")

@@ -25,12 +25,12 @@ python3 bench.py > gpurun_out/${R}_bench_compact.log 2>&1; grep '^{' gpurun_out/
 python3 bench.py --ae-form FC > gpurun_out/${R}_bench_fc.log 2>&1; grep '^{' gpurun_out/${R}_bench_fc.log > gpurun_out/${R}_bench_fc.json
 python3 tools/rank_scale.py > gpurun_out/${R}_rank_scale.log 2>&1
 # per block shape, every kernel ALONE (HIP events, all streams drained before each measurement)
-python3 bench.py --batch 4096 --rows 100000 --steps 80 --warmup 5 --cpu-budget 0 --no-epoch --no-configs2 --roofline-detail 2> /dev/null | grep '^{' > gpurun_out/${R}_bench_compact_b4096_per_shape.json
+python3 bench.py --batch 4096 --rows 100000 --steps 80 --warmup 5 --cpu-budget 0 --no-epoch --no-configs2 --no-trials --roofline-detail 2> /dev/null | grep '^{' > gpurun_out/${R}_bench_compact_b4096_per_shape.json
 # timelines of one step (rocprofv3 kernel trace -> tools/timeline.py): queues, gaps, overlap
 for wl in "compact_b256 --steps 100 --warmup 10" "compact_b4096 --batch 4096 --rows 100000 --steps 30 --warmup 5"; do
   set -- $wl; name=$1; shift
   (cd /tmp && export TMPDIR=/tmp && rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof_tl && mkdir -p $GRAFT_REPO_ROOT/gpurun_out/prof_tl && cd $GRAFT_REPO_ROOT &&
-   rocprofv3 --kernel-trace -d gpurun_out/prof_tl -o run -- python3 bench.py "$@" --cpu-budget 0 --no-roofline --no-epoch --no-configs2 > gpurun_out/prof_tl/bench.log 2>&1 &&
+   rocprofv3 --kernel-trace -d gpurun_out/prof_tl -o run -- python3 bench.py "$@" --cpu-budget 0 --no-roofline --no-epoch --no-configs2 --no-trials > gpurun_out/prof_tl/bench.log 2>&1 &&
    python3 tools/timeline.py $(find gpurun_out/prof_tl -name '*_results.db' | head -1) 3 all > gpurun_out/${R}_timeline_$name.txt; rm -rf gpurun_out/prof_tl)
 done
 ls -la gpurun_out/${R}_*

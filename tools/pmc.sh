@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd "$GRAFT_REPO_ROOT"
-rocprofv3 --kernel-trace --pmc $CTRS -d "$OUT" -o run -- python3 bench.py "$@" --cpu-budget 0 --no-roofline --no-epoch --no-configs2 > "$OUT/bench.log" 2>&1 || { tail -5 "$OUT/bench.log"; exit 1; }
+rocprofv3 --kernel-trace --pmc $CTRS -d "$OUT" -o run -- python3 bench.py "$@" --cpu-budget 0 --no-roofline --no-epoch --no-configs2 --no-trials > "$OUT/bench.log" 2>&1 || { tail -5 "$OUT/bench.log"; exit 1; }
 db=$(find "$OUT" -name '*_results.db' | head -1)
 cp "$db" "gpurun_out/${TAG}.db"
 rm -rf "$OUT"

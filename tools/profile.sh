@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd "$GRAFT_REPO_ROOT"
-rocprofv3 --kernel-trace --stats -d "$OUT" -o run -- python3 bench.py "$@" --cpu-budget 0 --no-roofline --no-epoch --no-configs2 > "$OUT/bench.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$OUT" -o run -- python3 bench.py "$@" --cpu-budget 0 --no-roofline --no-epoch --no-configs2 --no-trials > "$OUT/bench.log" 2>&1
 db=$(find "$OUT" -name '*_results.db' | head -1)
 python3 tools/kstats.py "$db" "gpurun_out/${TAG}_kernel_stats.csv"
 grep '^{' "$OUT/bench.log" > "gpurun_out/${TAG}_bench.json" || true
