@@ -73,6 +73,7 @@ def run_training(job_number, work_dir, train_config, verbose, data_file, timeout
         finally:
             if timer is not None:
                 timer.cancel()
+            trainer.engine.release()          # graphs, workspaces and streams back now: more trials follow in this process
         logger.info(metrics)
         time_used = time.time() - start
         logger.info(f"Training finished. Time used: {time_used:.2f}s.\n\n")
@@ -90,6 +91,7 @@ def run_training(job_number, work_dir, train_config, verbose, data_file, timeout
         metrics = trainer.train()
     finally:
         signal.setitimer(signal.ITIMER_REAL, 0.0)
+        trainer.engine.release()              # graphs, workspaces and streams back now: more trials may follow
     logger.info(metrics)
     time_used = time.time() - start
     logger.info(f"Training finished. Time used: {time_used:.2f}s.\n\n")

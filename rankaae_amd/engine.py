@@ -758,6 +758,21 @@ class StepEngine:
         self.graph_ar.close()
         self.graph_ar = None
 
+    def release(self):
+        """Give back what the engine holds on the device NOW -- captured graphs, workspaces, streams -- instead of when
+        the cyclic collector finds it (the engine sits in reference cycles with its networks).  A process that runs many
+        trials (``train_sc``) calls it after each; the engine cannot step afterwards.  The parameters (views of the
+        arena) stay valid for the exported modules."""
+        self.close()
+        if self._capture is not None or ops.Graph.active > 0:
+            return
+        torch.cuda.synchronize(self.device)
+        self.plans = {}
+        self._events = []
+        self.side_streams, self.aux_stream = [], None
+        self.G = None
+        self.tape = None
+
     def __del__(self):
         # the cyclic collector runs this at an arbitrary allocation point, possibly inside ANOTHER engine's capture
         # window in the same process (the next trial): close() refuses there, the communicator is then released with
