@@ -471,10 +471,13 @@ def main():
             gc.unfreeze()
             gc.collect()
             torch.cuda.empty_cache()
-        if not args.no_trials and world == 1 and b <= 1024:
-            line["concurrent_trials"] = trials_line(args, cfg, dev, spec, aux, tuple(int(x) for x in args.trials.split(",")))
+        # (configs2 first: its branched graph wants its streams on different hardware queues, and HIP hands queues out
+        # round-robin at stream creation -- behind the 13 engines of the trials sub-run it measured 174 steps/s instead
+        # of 255-275)
         if big:
             line["configs2"] = configs2_line(args, cfg, dev)
+        if not args.no_trials and world == 1 and b <= 1024:
+            line["concurrent_trials"] = trials_line(args, cfg, dev, spec, aux, tuple(int(x) for x in args.trials.split(",")))
         if args.cpu_budget > 0 and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg, spec, aux, args.cpu_budget)
             ratio = cpu_calibration(cfg["ae_form"])

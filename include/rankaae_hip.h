@@ -145,6 +145,12 @@ typedef struct {
 } raae_dense_bwd_t;
 int raae_dense_bwd_s(const raae_dense_bwd_t* p, int* nslab, void* stream);
 
+/* Experiment (build-only key `collapse_stats`, default off): the partial rows [n][C][2] of one or
+ * two BatchNorm statistics are added once into a single row [1][C][2] (one workgroup each), so that every consumer's
+ * prologue reads one row.  p2 == NULL: one statistic. */
+int raae_stat_collapse2(const double* p1, int n1, int C1, double* o1, const double* p2, int n2, int C2, double* o2,
+                        void* stream);
+
 /* Final BatchNorm1d(nstyle, affine=False) of both encoders (model.py:284,366):
  * styles = BN(z).  Backward: dz from dstyles (torch batch_norm backward, train mode). */
 int raae_style_bn_fwd(const float* z, int B, int C, const raae_bn_t* bn, float* styles, void* stream);

@@ -170,6 +170,7 @@ SIGNATURES = {
     "raae_dense_bwd_st": (_I, [_P, _I, _P, _I, _P, _P, _PB, _I, _I, _P, _I, _I, _P, _PB, _P, _P,
                                _P, _P, _P, _L, _PI, _P, _P, _I, _P]),
     "raae_dense_bwd_s": (_I, [C.POINTER(DenseBwdT), _PI, _P]),
+    "raae_stat_collapse2": (_I, [_P, _I, _I, _P, _P, _I, _I, _P, _P]),
     "raae_style_bn_fwd": (_I, [_P, _I, _I, _PB, _P, _P]),
     "raae_style_bn_bwd": (_I, [_P, _P, _I, _I, _PB, _F, _P, _P]),
     "raae_rank_loss_work_bytes": (_L, [_I, _I]),

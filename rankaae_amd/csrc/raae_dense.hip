@@ -11,6 +11,7 @@
 // statistics and parameter gradients leave the kernel as fixed-order per-workgroup
 // partials (double) / slabs (float): no atomics, bitwise reproducible.
 #include "raae_common.h"
+#include <stddef.h>
 #include <hip/hip_bf16.h>
 
 #ifdef RAAE_STAMPS
@@ -353,9 +354,14 @@ __device__ __forceinline__ void dense_fwd_body(const DenseFwdArgs& a, const int 
     dense_fwd_tiles<KQ, RT, ST>(a, bx, by, gx, smem, ms);
 }
 
+// (the by-value argument block goes to LDS in one coalesced vector load, raae::args_to_lds: scalar loads of a 200-300-byte
+// struct out of a fresh kernarg buffer are a chain of dependent misses at the head of a 6-us kernel -- the fused block
+// kernels have done this since round 1)
 template <int KQ, int RT = 1, bool ST = false>
-__global__ __launch_bounds__(256) void dense_fwd_kernel(DenseFwdArgs a) {
+__global__ __launch_bounds__(256) void dense_fwd_kernel(DenseFwdArgs ka) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ DenseFwdArgs sa;
+    const DenseFwdArgs& a = raae::args_to_lds(&sa);
     dense_fwd_body<KQ, RT, ST>(a, blockIdx.x, blockIdx.y, gridDim.x, smem);
 }
 
@@ -365,12 +371,15 @@ struct DenseFwd2Args { DenseFwdArgs x; DenseFwdArgs y; int n1; int gx1; int gx2;
 template <int Q1, int Q2>
 __global__ __launch_bounds__(256, 1) void dense_fwd2_kernel(DenseFwd2Args k) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ DenseFwdArgs sa;
     int b = blockIdx.x;
     if (b < k.n1) {
-        dense_fwd_body<Q1>(k.x, b % k.gx1, b / k.gx1, k.gx1, smem);
+        const DenseFwdArgs& a = raae::args_to_lds_at(&sa, (int)offsetof(DenseFwd2Args, x));
+        dense_fwd_body<Q1>(a, b % k.gx1, b / k.gx1, k.gx1, smem);
     } else {
         b -= k.n1;
-        dense_fwd_body<Q2>(k.y, b % k.gx2, b / k.gx2, k.gx2, smem);
+        const DenseFwdArgs& a = raae::args_to_lds_at(&sa, (int)offsetof(DenseFwd2Args, y));
+        dense_fwd_body<Q2>(a, b % k.gx2, b / k.gx2, k.gx2, smem);
     }
 }
 
@@ -443,8 +452,10 @@ __device__ __forceinline__ void stage_rows(float* Xs, int pitch, const float* x,
 // A first layer (K = 256 / 512 input points, no input transform) is split over blockIdx.y in slices of kw columns: more
 // workgroups for the launch-bound batches and a dW tile set of 8 tiles per wave (19.4 -> 12.0 us at 256 rows).
 template <int TPW, int KT4, bool ST = false>
-__global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs a) {
+__global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs ka) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ DenseBwdArgs sa;
+    const DenseBwdArgs& a = raae::args_to_lds(&sa);       // (see dense_fwd_kernel)
     const int st = ST ? a.storage : 0;
     const int k0 = blockIdx.y * a.kw, Kl = a.kw;      // this workgroup's input columns [k0, k0 + Kl)
     const int N16 = (a.N + 15) & ~15, K16 = (Kl + 15) & ~15;

@@ -507,6 +507,19 @@ __global__ void gather_batch_kernel(const float* spec, const float* aux, const l
     }
 }
 
+// ------------------------------------------------------------------ collapse of partial statistics (experiment)
+// one workgroup per statistic adds the <= 512 partial rows {sum, sum of squares} once, so that
+// every consumer's prologue reads ONE row.  Fixed order (reduce_partials) => deterministic.
+__global__ __launch_bounds__(256) void stat_collapse_kernel(const double* p1, int n1, int C1, double* o1,
+                                                            const double* p2, int n2, int C2, double* o2) {
+    __shared__ double tot_s[256], tot_q[256];
+    const double* p = blockIdx.x == 0 ? p1 : p2;
+    const int n = blockIdx.x == 0 ? n1 : n2, C = blockIdx.x == 0 ? C1 : C2;
+    double* o = blockIdx.x == 0 ? o1 : o2;
+    raae::reduce_partials(p, n, C, tot_s, tot_q);
+    if ((int)threadIdx.x < C) { o[2 * threadIdx.x] = tot_s[threadIdx.x]; o[2 * threadIdx.x + 1] = tot_q[threadIdx.x]; }
+}
+
 int grid_for(long n, int per_block, int cap) {
     long g = (n + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -527,6 +540,14 @@ extern "C" int raae_style_bn_bwd(const float* dstyles, const float* styles, int 
     RAAE_CHECK_ARG(dstyles && styles && bn && dz && B > 0 && C > 0 && C <= 64 && bn->nparts <= RAAE_MAX_PARTS);
     hipLaunchKernelGGL(style_bn_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dstyles, styles, B, C, *bn,
                        scale, dz);
+    RAAE_LAUNCH_RET();
+}
+
+extern "C" int raae_stat_collapse2(const double* p1, int n1, int C1, double* o1, const double* p2, int n2, int C2, double* o2,
+                                   void* stream) {
+    RAAE_CHECK_ARG(p1 && o1 && n1 > 0 && n1 <= RAAE_MAX_PARTS && C1 > 0 && C1 <= 256);
+    RAAE_CHECK_ARG(!p2 || (o2 && n2 > 0 && n2 <= RAAE_MAX_PARTS && C2 > 0 && C2 <= 256));
+    hipLaunchKernelGGL(stat_collapse_kernel, dim3(p2 ? 2 : 1), dim3(256), 0, (hipStream_t)stream, p1, n1, C1, o1, p2, n2, C2, o2);
     RAAE_LAUNCH_RET();
 }
 

@@ -557,6 +557,10 @@ class StepEngine:
         # build-only key `inline_masks` (rng_mode "philox" only; default on): dropout multipliers are regenerated by
         # the kernels that apply them instead of written to and read from the random tape
         self.inline_masks = self.rng_mode == "philox" and bool(cfg.get("inline_masks", True))
+        # experiment, build-only key `collapse_stats` (default off): the forwards whose backward
+        # follows collapse their BatchNorm partial rows into one row for the three to five consumers of each statistic
+        self.collapse_stats = bool(cfg.get("collapse_stats", False))
+        self.collapse_min_rows = int(cfg.get("collapse_min_rows", 64))
         # build-only key `fused_step_begin` (default on): the head of a step -- counters, tape fill, batch gather and
         # spectral noise -- is one launch (raae_step_begin) instead of three
         self.fused_begin = bool(cfg.get("fused_step_begin", True))
@@ -965,8 +969,14 @@ class StepEngine:
                              float(c["spec_noise"]), b, self.L, self.n_aux, P.spec, P.aux)
         enc, dec, E, D = self.enc, self.dec, P.enc, P.dec
         lo = self.loss_out
+
+        def will_backprop(*nets):       # `collapse_stats`: the next forward of these networks is followed by its backward
+            for net in (enc, dec):
+                net.collapse = self.collapse_stats and net in nets
         # trainer.py:113-114
+        will_backprop(enc)
         styles = enc.forward(E, P.spec, P.m_enc[0])
+        will_backprop()
         # The reference discards this decoder output (BatchNorm statistics and RNG draws are its only effects).
         # Serial chain: it is deferred to phase B, where it runs in lockstep with the encoder forward (one launch
         # per pair of block kernels) -- phase A updates neither the decoder nor, before that forward's last
@@ -988,17 +998,21 @@ class StepEngine:
         self._adam(P, "adversarial", self._slab_notes)
         # ---- phase B: rank correlation (:153-161)
         self._begin_phase(record)
+        will_backprop(enc)
         if pair:
             styles, _ = enc.forward_pair(enc.forward_steps(E, P.spec, P.m_enc[1]), dec.forward_steps(D, styles, P.m_dec[0]))
         else:
             styles = enc.forward(E, P.spec, P.m_enc[1])
+        will_backprop()
         self._rank_loss(P, styles)
         enc.backward(E, P.spec, P.m_enc[1], P.dstyles)
         self._adam(P, "correlation", self._slab_notes)
         # ---- phase C: reconstruction (:164-172)
         self._begin_phase(record)
+        will_backprop(enc, dec)
         styles = enc.forward(E, P.spec, P.m_enc[2])
         out = dec.forward(D, styles, P.m_dec[1])
+        will_backprop()
         ops.recon_loss_fwd_bwd(P.spec, out, b, self.L, c["use_flex_spec_target"], P.lpart, P.dout,
                                fin=(1.0, lo, 2, -1, P.ticket))
         left = dec.backward(D, styles, P.m_dec[1], P.dout, P.dstyles, keep_pending=True)
@@ -1007,6 +1021,7 @@ class StepEngine:
         # ---- phase D: mutual information (:175-186)
         self._begin_phase(record)
         z_s = tape.view(P.z_sample, b, ns)
+        will_backprop(dec)               # (the encoder forward of this pair is the one the reference discards)
         if pair:
             # the encoder forward whose result the reference does not use (BN stats + RNG only) and the decoder
             # forward, which only needs z_sample, in lockstep: one launch per pair of block kernels
@@ -1016,7 +1031,9 @@ class StepEngine:
                 enc.forward(E, P.spec, P.m_enc[3])
             out = dec.forward(D, z_s, P.m_dec[2])
             self.join_aux()
+        will_backprop(enc)
         z_rec = enc.forward(E, out, P.m_enc[4])
+        will_backprop()
         ops.mse_fwd_bwd(z_rec, z_s, b * ns, P.lpart, P.dstyles, fin=(1.0, lo, 3, 5, P.ticket))
         left = enc.backward(E, out, P.m_enc[4], P.dstyles, P.dspec, keep_pending=True)
         dec.backward(D, z_s, P.m_dec[2], P.dspec, None, pending=left)
@@ -1024,8 +1041,10 @@ class StepEngine:
         # ---- phase E: smoothness (:189-200); encoder gradients are discarded by the reference
         if smooth:
             self._begin_phase(record)
-            styles = enc.forward(E, P.spec, P.m_enc[5])
+            styles = enc.forward(E, P.spec, P.m_enc[5])        # (its gradients are discarded: no backward)
+            will_backprop(dec)
             out = dec.forward(D, styles, P.m_dec[3])
+            will_backprop()
             ops.smooth_loss_fwd_bwd(out, b, self.L, self.taps, P.lpart, P.dout, fin=(1.0, lo, 4, -1, P.ticket))
             dec.backward(D, styles, P.m_dec[3], P.dout, None)
             self._adam(P, "smoothness", self._slab_notes)

@@ -100,7 +100,11 @@ class CompactNet:
             w.E1, w.E2 = t(b, k.Cin, k.E), t(b, k.Cin, k.Lout)
             w.E3 = t(b, k.Cout, k.Lout) if k.cve is not None else None
             w.Y = t(b, k.Cout, k.Lout)
-            w.pT1, w.pE2, w.pY = parts(k.Cout), parts(k.Cin), parts(k.Cout)
+            # r*: the partial rows the producers write; p*: what the consumers read -- the same rows, or (experiment
+            # `collapse_stats`) one row into which raae_stat_collapse2 has added them (c*)
+            w.rT1, w.rE2, w.rY = parts(k.Cout), parts(k.Cin), parts(k.Cout)
+            w.cT1, w.cE2, w.cY = (torch.zeros(1, C_, 2, dtype=torch.float64, device=dev) for C_ in (k.Cout, k.Cin, k.Cout))
+            w.pT1, w.pE2, w.pY = w.rT1, w.rE2, w.rY
             w.nT1 = w.nE2 = w.nY = 0
             w.dBn2, w.pdBn2 = t(b, k.Cout, k.L1), parts(k.Cout)
             w.dR, w.pdR = t(b, k.Cin, k.Lin), parts(k.Cin)
@@ -218,9 +222,17 @@ class CompactNet:
             if fused:
                 # two kernels per block: everything that only needs bn1, then everything that needs bn2 / bn_excit
                 mask_i = self._mask(masks, i, train)
-                n1 = yield ("a", ops.block_fwd_a_args(vR(True), mask_i, b, k, m, w.T1, w.Sh, w.E1, w.E2, w.pT1,
-                                                      w.pE2 if k.cve is not None else None), 0)
-                w.nT1 = w.nE2 = n1
+                n1 = yield ("a", ops.block_fwd_a_args(vR(True), mask_i, b, k, m, w.T1, w.Sh, w.E1, w.E2, w.rT1,
+                                                      w.rE2 if k.cve is not None else None), 0)
+                w.pT1, w.pE2, w.nT1, w.nE2 = w.rT1, w.rE2, n1, n1
+                collapse = train and getattr(self, "collapse", False) and n1 >= self.eng.collapse_min_rows
+                if collapse:
+                    if k.cve is not None:
+                        ops.stat_collapse2(w.rT1, n1, k.Cout, w.cT1, w.rE2, n1, k.Cin, w.cE2)
+                        w.pE2, w.nE2 = w.cE2, 1
+                    else:
+                        ops.stat_collapse2(w.rT1, n1, k.Cout, w.cT1)
+                    w.pT1, w.nT1 = w.cT1, 1
                 v1 = ops.make_view(w.T1, m.relu1.weight, self._bn(m.bn2, w.pT1, w.nT1, b * k.L1, train, True))
                 if k.cve is not None:
                     ve2 = ops.make_view(w.E2, m.relu_excit_2.weight,
@@ -228,9 +240,14 @@ class CompactNet:
                 else:
                     ve2 = ops.make_view(w.E2, m.relu_excit_2.weight)
                 w.nY = yield ("b", ops.block_fwd_b_args(v1, ve2, vR(False) if k.cvs is None else None, b, k, m, w.Sh,
-                                                        w.T2, w.E3, w.Y, w.pY), 0)
+                                                        w.T2, w.E3, w.Y, w.rY), 0)
+                w.pY = w.rY
+                if collapse:
+                    ops.stat_collapse2(w.rY, w.nY, k.Cout, w.cY)
+                    w.pY, w.nY = w.cY, 1
                 X, pX, nX = w.Y, w.pY, w.nY
                 continue
+            w.pT1, w.pE2, w.pY = w.rT1, w.rE2, w.rY          # (per-layer path: never collapsed)
             w.nT1 = ops.conv_fwd(vR(True), b, k.cv1, m.conv1.weight, m.conv1.bias, w.T1, OUT_STATS_PRELU,
                                  m.relu1.weight, w.pT1)
             v1 = ops.make_view(w.T1, m.relu1.weight, self._bn(m.bn2, w.pT1, w.nT1, b * k.L1, train, True))

@@ -174,6 +174,14 @@ def dense_bwd(g, g_kind, g_partials, g_nparts, zout, out_slope, out_bn, B, N, x,
     return _probed("dense_bwd_kernel", nbytes, launch)
 
 
+def stat_collapse2(p1, n1, C1, o1, p2=None, n2=0, C2=0, o2=None):
+    def launch():
+        check(_lib.load().raae_stat_collapse2(_ptr(p1, torch.float64), n1, C1, _ptr(o1, torch.float64),
+                                              _ptr(p2, torch.float64), n2, C2, _ptr(o2, torch.float64), _stream()),
+              "raae_stat_collapse2")
+    _probed("stat_collapse_kernel", 16 * (n1 * C1 + n2 * C2), launch)
+
+
 def style_bn_fwd(z, B, Cc, bn, styles):
     check(_lib.load().raae_style_bn_fwd(_ptr(z), B, Cc, _bnp(bn), _ptr(styles), _stream()), "raae_style_bn_fwd")
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything under profiles/ for one round, in one gpurun call:  gpurun --timeout 1150 -- 'bash tools/collect_profiles.sh r2'
 # (kernel-trace statistics, FETCH_SIZE / WRITE_SIZE in separate --pmc passes, one MFMA counter pass, bench lines)
-R=${1:-r2}
+R=${1:-r3}
 set -x
 bash tools/profile.sh ${R}_compact_b256 --steps 200 --warmup 20 > /dev/null
 bash tools/profile.sh ${R}_compact_b4096 --batch 4096 --rows 100000 --steps 30 --warmup 5 > /dev/null
