@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void step_begin_kernel(StepBeginArgs a) {
     // ticket -- at the START (the value comes back while the workgroup works): whoever draws the last one knows that
     // every workgroup has READ the counters (the LDS stores need the loaded values, and precede the ticket in program
     // order) and publishes the advanced ones at its end.  (Tickets of one address serialise at ~40 ns each: 2048
-    // workgroups taking them at their END made this kernel 84 us long; the grid is now 64 ... 512 workgroups.)
+    // workgroups taking them at their END made this kernel 84 us long; the grid is now 64 ... 1024 workgroups.)
     __shared__ unsigned long long s_ctr, s_seed;
     __shared__ int s_cur;
     unsigned my_ticket = 0u;
@@ -338,8 +338,8 @@ extern "C" int raae_step_begin(const raae_step_begin_t* p, void* stream) {
     a.nseg = p->nseg; a.total = p->nseg > 0 ? p->total : 0;
     long work = (long)p->B * p->L / 4;
     if (a.total / 4 > work) work = a.total / 4;
-    long g = (work + 4095) / 4096;          // ~16 quads per thread
-    if (g > 512) g = 512;
+    long g = (work + 4095) / 4096;          // ~16 quads per thread ...
+    if (g > 1024) g = 1024;                 // ... up to 1024 workgroups (their tickets, ~40 us, come back during ~45 us of fill at 4096 rows)
     if (g < 64) g = 64;
     hipLaunchKernelGGL(step_begin_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, a);
     RAAE_LAUNCH_RET();

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Timeline of ONE training step from a rocprofv3 rocpd database: every kernel between two launches of the step's first
-kernel (rng_fill_kernel), in start order, with its duration, the idle gap before it on its own queue, and how much of
+kernel (step_begin_kernel; rng_fill_kernel before round 3), in start order, with its duration, the idle gap before it on its own queue, and how much of
 the step's wall time had at least one kernel running.  Usage: timeline.py results.db [step index from the end = 2]"""
 import re
 import sqlite3
@@ -21,7 +21,9 @@ def main():
     name = "name" if "name" in cols else "kernel_name"
     qcol = next((c for c in ("queue_id", "queue", "stream_id", "stream") if c in cols), None)
     rows = db.execute(f"select {name}, start, end, {qcol or 0} from kernels order by start").fetchall()
-    marks = [i for i, r in enumerate(rows) if "rng_fill" in r[0]]
+    marks = [i for i, r in enumerate(rows) if "step_begin_kernel" in r[0]]
+    if len(marks) < 3:      # a build without the fused step head
+        marks = [i for i, r in enumerate(rows) if "rng_fill" in r[0] or "tick_kernel" in r[0]]
     lo, hi = marks[-back - 1], marks[-back]
     step = rows[lo:hi]
     t0, t1 = step[0][1], rows[hi][1]
