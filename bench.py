@@ -324,10 +324,53 @@ def trials_line(args, cfg, dev, spec, aux, counts=(1, 4, 8), rounds=150):
         gc.collect()
         torch.cuda.empty_cache()
     base = out[str(counts[0])]
-    return {"unit": "five-phase steps/s summed over T concurrent independent trials on ONE GPU (one engine, stream and "
-                    "hipGraph per trial, one host thread)", "batch": b, "aggregate_steps_per_s": out,
-            "speedup_vs_one_trial": {k: round(v / base, 2) for k, v in out.items()},
-            "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)")}
+    res = {"unit": "five-phase steps/s summed over T concurrent independent trials on ONE GPU (one engine, stream and "
+                   "hipGraph per trial, one host thread)", "batch": b, "aggregate_steps_per_s": out,
+           "speedup_vs_one_trial": {k: round(v / base, 2) for k, v in out.items()},
+           "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)")}
+    if cfg["ae_form"] == "FC":
+        # the dense networks' kernels also exist in a batched form: ONE launch sequence, gridDim.z = T
+        # (rankaae_amd.trial_batch.TrialBatch); each trial bit for bit what it is alone
+        from rankaae_amd.trial_batch import TrialBatch
+        bout = {}
+        for T in tuple(counts) + ((16,) if 16 not in counts else ()):
+            shared = TrialBatch.shared_stream(dev)
+            engs = []
+            for t in range(T):
+                enc, dec, dis = build_models(cfg, 1234 + t)
+                e = StepEngine(enc, dec, dis, cfg, dev, rng_mode="philox", seed=99 + t, use_graph=True, stream=shared)
+                e.set_data(spec[:n_train], aux[:n_train])
+                engs.append(e)
+            batch = TrialBatch(engs)
+            gen = torch.Generator().manual_seed(7)
+            i = 0
+
+            def one_round():
+                nonlocal i
+                if i % full == 0:
+                    for e in engs:
+                        e.set_epoch(torch.randperm(n_train, generator=gen), 0.7172)
+                batch.step(b, smooth=True)
+                i += 1
+            for _ in range(6):
+                one_round()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(rounds):
+                one_round()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            bout[str(T)] = round(T * rounds / dt, 1)
+            batch.release()
+            for e in engs:
+                e.release()
+            del engs, batch
+            gc.collect()
+            torch.cuda.empty_cache()
+        res["batched_launches"] = {"unit": "the same, the T trials stepped by ONE launch sequence with gridDim.z = T "
+                                           "(TrialBatch; dense networks)", "aggregate_steps_per_s": bout,
+                                   "speedup_vs_one_trial": {k: round(v / base, 2) for k, v in bout.items()}}
+    return res
 
 
 def main():

@@ -473,6 +473,23 @@ typedef struct {
 } raae_step_begin_t;
 int raae_step_begin(const raae_step_begin_t* p, void* stream);
 
+/* ---- independent trials batched into one launch (reference: sc/cmd/train_sc.py:127-143 maps `trials` over
+ * engines) ----
+ * The entry points of the dense-network path (raae_step_begin, raae_dense_fwd_s / _fwd2 / _bwd_s, raae_style_bn_*,
+ * raae_disc_fused, raae_rank_loss_fwd_bwd, the three loss kernels, raae_adam_step) exist in a second form whose grid
+ * plane z works on trial z's argument block.  raae_record_begin/end log the launches one trial makes on the calling
+ * thread (they still run); raae_multi_build takes the logs of T structurally identical trials and uploads, launch by
+ * launch, the T argument blocks as one table (RAAE_EINVAL when the logs differ in kernel instance, geometry or LDS);
+ * raae_multi_launch replays the program with gridDim.z = T on `stream` (capturable).  A trial's arithmetic is the body
+ * it runs alone: results are bit-identical. */
+int raae_record_begin(void);
+int raae_record_end(void** handle, int* n_launches);
+int raae_record_free(void* handle);
+int raae_multi_build(void* const* handles, int T, void** program);
+int raae_multi_launch(void* program, void* stream);
+int raae_multi_count(void* program);
+int raae_multi_free(void* program);
+
 /* ---- stream / graph / event plumbing (HIP runtime; used by the engine and bench.py) ---- */
 int raae_graph_begin(void* stream);
 int raae_graph_end(void* stream, void** graph_exec);
@@ -485,7 +502,7 @@ int raae_event_destroy(void* ev);
 int raae_stream_sync(void* stream);
 const char* raae_error_string(int code);
 int raae_device_info(int* cu_count, int* lds_bytes, char* name, int name_len);
-#define RAAE_ABI_VERSION 13
+#define RAAE_ABI_VERSION 14
 int raae_abi_version(void);
 /* First 16 hex digits of sha256 over include/rankaae_hip.h + csrc/raae_*.{h,inc,hip} at build time
  * (build.sh); the Python loader recomputes it and refuses a library built from other sources. */

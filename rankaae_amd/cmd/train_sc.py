@@ -6,7 +6,10 @@ engine.  The ipyparallel engine farm (``train_sc.py:19-45``) becomes one worker 
 trial ``k`` runs on worker ``k mod n`` and worker ``w`` uses GPU ``w mod ngpus`` (``RANKAAE_TRIAL_WORKERS``
 overrides ``n``).  Several trials share a GPU (config key ``trials_per_gpu``, default 4 when ``trials > 1``): a 256-row
 step is one serial chain of ~10 us kernels that leaves most of the chip idle, and the chains of independent trials
-overlap on it.  ``trial_mode: threads`` (default): the trials of a worker run in threads of ONE process -- one engine,
+overlap on it.  ``trial_mode: auto`` (default) picks ``batched`` for the dense networks -- the trials of a group train in
+LOCKSTEP and every training step of the group is ONE launch sequence whose kernels run with ``gridDim.z = trials``
+(``rankaae_amd/trial_batch.py``; 6.2x the single-trial rate at 8 trials, 10x at 16) -- and ``threads`` for the conv
+networks.  ``trial_mode: threads``: the trials of a worker run in threads of ONE process -- one engine,
 HIP stream and captured graph per trial, all of them feeding the same device; every trial draws from its own host
 generator (seeded ``trial_seed + k``; ``trial_seed`` defaults to a draw from the global generator), so a trial's result
 does not depend on what runs beside it (tests/test_trainer_gpu.py).  ``trial_mode: processes``: one worker process per
@@ -116,13 +119,63 @@ def assign_trials(trials, nworkers):
     return [list(range(w, trials, nworkers)) for w in range(nworkers)]
 
 
-def _trial_worker(worker, jobs, work_dir, config_dict, verbose, data_file, timeout, threads=1, trial_seed=None):
+def _trial_worker(worker, jobs, work_dir, config_dict, verbose, data_file, timeout, threads=1, trial_seed=None, batched=False):
     # a spawned process: nothing has touched the GPU yet; LOCAL_RANK picks it in run_training
     os.environ["LOCAL_RANK"] = str(worker)
     cfg = Parameters(config_dict)
+    if batched:
+        return run_trials_batched(jobs, threads, work_dir, cfg, verbose, data_file, timeout, trial_seed)
     if threads <= 1:
         return [(k,) + tuple(run_training(k, work_dir, cfg, verbose, data_file, timeout)) for k in jobs]
     return run_trials_threaded(jobs, threads, work_dir, cfg, verbose, data_file, timeout, trial_seed)
+
+
+def run_trials_batched(jobs, per_batch, work_dir, train_config, verbose, data_file, timeout, trial_seed):
+    """The trials ``jobs`` of this process, ``per_batch`` at a time, each group trained in LOCKSTEP: every training step
+    of the group is one launch sequence with ``gridDim.z = trials`` (``rankaae_amd.trainer.train_trials_batched``; dense
+    networks).  Seeds, files and log lines per trial as in the thread mode: ``[(k, metrics, time_used)]``."""
+    from rankaae_amd.trainer import train_trials_batched
+    ngpus = torch.cuda.device_count()
+    local_id = int(os.environ.get("LOCAL_RANK", os.environ.get("SLURM_LOCALID", 0)))
+    igpu = local_id % ngpus if ngpus > 0 else -1
+    out = []
+    for i in range(0, len(jobs), per_batch):
+        group = jobs[i:i + per_batch]
+        torch.cuda.set_device(max(igpu, 0))
+        stream = torch.cuda.Stream()
+        trainers, loggers = [], []
+        start = time.time()
+        for k in group:
+            wd = f"{work_dir}/training/job_{k + 1}"
+            os.makedirs(wd, exist_ok=True)
+            logger = create_logger(f"subtraining_{k + 1}", os.path.join(wd, "messages.txt"))
+            loss_logger = create_logger(f"losses_{k + 1}", os.path.join(wd, "losses.csv"), simple_fmt=True)
+            logger.info(f"Training started for trial {k + 1}.")
+            g = torch.Generator()
+            g.manual_seed(int(trial_seed) + k)
+            torch.manual_seed(g.initial_seed())          # the networks' initial weights come from the global generator
+            trainers.append(Trainer.from_data(data_file, igpu=igpu, verbose=verbose, work_dir=wd,
+                                              config_parameters=train_config, logger=logger, loss_logger=loss_logger,
+                                              host_rng=g, engine_stream=stream))
+            loggers.append(logger)
+        timer = None
+        if timeout > 0:
+            timer = threading.Timer(float(timeout) * 3600.0, lambda: [t.request_stop("Training Overtime!") for t in trainers])
+            timer.daemon = True
+            timer.start()
+        try:
+            metrics = train_trials_batched(trainers)
+        finally:
+            if timer is not None:
+                timer.cancel()
+            for t in trainers:
+                t.engine.release()
+        time_used = time.time() - start
+        for k, m, logger in zip(group, metrics, loggers):
+            logger.info(m)
+            logger.info(f"Training finished. Time used: {time_used:.2f}s.\n\n")
+            out.append((k, m, time_used))
+    return out
 
 
 def run_trials_threaded(jobs, threads, work_dir, train_config, verbose, data_file, timeout, trial_seed):
@@ -147,13 +200,25 @@ def run_trials(trials, work_dir, train_config, verbose, data_file, timeout, logg
     """All trials; returns ``[(metrics, time_used)]`` in trial order and the number of worker processes."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     nworkers = 1
-    mode = str(train_config.get("trial_mode", "threads"))
-    if mode not in ("threads", "processes"):
-        raise ValueError(f"trial_mode must be 'threads' or 'processes', not {mode!r}")
+    mode = str(train_config.get("trial_mode", "auto"))
+    if mode not in ("auto", "batched", "threads", "processes"):
+        raise ValueError(f"trial_mode must be 'auto', 'batched', 'threads' or 'processes', not {mode!r}")
+    philox = train_config.get("rng_mode", "philox") == "philox"
+    can_batch = (train_config.get("ae_form", None) == "FC" and philox and train_config.get("precision", "fp32") == "fp32" and
+                 train_config.get("fused_step_begin", True) and train_config.get("fused_discriminator", True))
+    if mode == "batched" and not can_batch:
+        raise ValueError("trial_mode: batched needs ae_form: FC, rng_mode: philox, precision: fp32 (the kernels of the "
+                         "dense-network step have the batched form; the conv networks use trial_mode: threads)")
+    if mode == "auto":      # dense networks: one launch sequence for all trials of a group; conv networks: threads
+        mode = "batched" if can_batch else "threads"
+    batched = mode == "batched"
+    if batched:
+        mode = "threads"          # same process / seed plumbing below; the worker trains its group in lockstep instead
     seeded = train_config.get("trial_seed", None) is not None
-    if world == 1 and (trials > 1 or seeded) and mode == "threads" and train_config.get("rng_mode", "philox") == "philox":
-        # one worker process per GPU; inside it `trials_per_gpu` trials at a time in threads
-        per_gpu = int(os.environ.get("RANKAAE_TRIALS_PER_GPU", train_config.get("trials_per_gpu", 4)))
+    if world == 1 and (trials > 1 or seeded) and mode == "threads" and philox:
+        # one worker process per GPU; inside it `trials_per_gpu` trials at a time: in threads, or (dense networks) as
+        # one batched launch sequence -- eight trials of a 256-row dense step still fit the chip side by side
+        per_gpu = int(os.environ.get("RANKAAE_TRIALS_PER_GPU", train_config.get("trials_per_gpu", 8 if batched else 4)))
         ngpu = max(1, torch.cuda.device_count())
         nproc = max(1, min(int(os.environ.get("RANKAAE_TRIAL_WORKERS", ngpu)), trials))
         threads = max(1, min(per_gpu, -(-trials // nproc)))
@@ -161,13 +226,13 @@ def run_trials(trials, work_dir, train_config, verbose, data_file, timeout, logg
         if seed is None:
             seed = int(torch.empty((), dtype=torch.int64).random_().item()) & 0x3fffffff
         if nproc == 1:
-            done = sorted(run_trials_threaded(list(range(trials)), threads, work_dir, train_config, verbose, data_file,
-                                              timeout, seed))
+            run = run_trials_batched if batched else run_trials_threaded
+            done = sorted(run(list(range(trials)), threads, work_dir, train_config, verbose, data_file, timeout, seed))
             return [(m, t) for _, m, t in done], threads
         import multiprocessing as mp
         with mp.get_context("spawn").Pool(nproc) as pool:
             parts = pool.starmap(_trial_worker, [(w, jobs, work_dir, train_config.to_dict(), verbose, data_file, timeout,
-                                                  threads, seed) for w, jobs in enumerate(assign_trials(trials, nproc))])
+                                                  threads, seed, batched) for w, jobs in enumerate(assign_trials(trials, nproc))])
         done = sorted(r for part in parts for r in part)
         return [(m, t) for _, m, t in done], nproc * threads
     if world == 1 and trials > 1:

@@ -298,6 +298,31 @@ __device__ __forceinline__ void stat_jobs(const StatJob (&jobs)[N], bool is_bloc
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// ---- batched launches over independent TRIALS (the reference's workload is `trials: 8` small models) ----
+// A kernel that supports it exists twice: K(Args) for one trial and K_m(const Args* table), launched with
+// gridDim.z = T, whose workgroups of plane z take table[z] -- the SAME body, the same blockIdx.x / gridDim.x, so a
+// trial's arithmetic is bit for bit what it is alone.  raae::launch() launches K and, while the calling thread is
+// recording (raae_record_begin), logs {K_m, grid, block, LDS, the argument block}; raae_multi_build() checks that the
+// logs of T trials agree launch by launch and uploads the T argument blocks of every launch as one device table;
+// raae_multi_launch() replays the program with gridDim.z = T (capturable into a hipGraph).
+void record_launch(const void* multi_fn, dim3 grid, dim3 block, size_t lds, const void* args, size_t nbytes);
+template <typename A>
+inline void launch(void (*single)(A), void (*multi)(const A*), dim3 grid, dim3 block, size_t lds, hipStream_t st, const A& a) {
+    record_launch(reinterpret_cast<const void*>(multi), grid, block, lds, &a, sizeof(A));
+    hipLaunchKernelGGL(single, grid, block, lds, st, a);
+}
+// plane z's argument block -> LDS in one coalesced load (the table counterpart of args_to_lds)
+template <typename T>
+__device__ __forceinline__ const T& args_from_ptr(T* slot, const T* entry) {
+    const unsigned* src = reinterpret_cast<const unsigned*>(entry);
+    unsigned* dst = reinterpret_cast<unsigned*>(slot);
+    for (int i = threadIdx.x; i < (int)(sizeof(T) / 4); i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+    return *slot;
+}
+template <typename T>
+__device__ __forceinline__ const T& args_from_table(T* slot, const T* table) { return args_from_ptr(slot, table + blockIdx.z); }
+
 // ---- dropout multipliers from a counter-based hash (rng_mode "philox") ---------------------------------------------
 // A dropout multiplier carries ONE bit.  Instead of a Philox block per four multipliers written to a fp32 tape and read
 // back by every consumer (146 MB per step at 4096 rows), element e of the step's random tape is

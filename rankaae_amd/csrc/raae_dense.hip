@@ -365,6 +365,14 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(DenseFwdArgs ka) {
     dense_fwd_body<KQ, RT, ST>(a, blockIdx.x, blockIdx.y, gridDim.x, smem);
 }
 
+template <int KQ, int RT = 1, bool ST = false>
+__global__ __launch_bounds__(256) void dense_fwd_kernel_m(const DenseFwdArgs* table) {     // one trial per grid plane
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ DenseFwdArgs sa;
+    const DenseFwdArgs& a = raae::args_from_table(&sa, table);
+    dense_fwd_body<KQ, RT, ST>(a, blockIdx.x, blockIdx.y, gridDim.x, smem);
+}
+
 // Two independent layers (one of the encoder, one of the decoder: the forward chain whose result the reference
 // discards beside one that is needed) in ONE launch: workgroups [0, n1) run the first, the rest the second.
 struct DenseFwd2Args { DenseFwdArgs x; DenseFwdArgs y; int n1; int gx1; int gx2; };
@@ -380,6 +388,22 @@ __global__ __launch_bounds__(256, 1) void dense_fwd2_kernel(DenseFwd2Args k) {
         b -= k.n1;
         const DenseFwdArgs& a = raae::args_to_lds_at(&sa, (int)offsetof(DenseFwd2Args, y));
         dense_fwd_body<Q2>(a, b % k.gx2, b / k.gx2, k.gx2, smem);
+    }
+}
+template <int Q1, int Q2>
+__global__ __launch_bounds__(256, 1) void dense_fwd2_kernel_m(const DenseFwd2Args* table) {     // one trial per grid plane
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ DenseFwdArgs sa;
+    const DenseFwd2Args* k = table + blockIdx.z;
+    const int n1 = k->n1, gx1 = k->gx1, gx2 = k->gx2;
+    int b = blockIdx.x;
+    if (b < n1) {
+        const DenseFwdArgs& a = raae::args_from_ptr(&sa, &k->x);
+        dense_fwd_body<Q1>(a, b % gx1, b / gx1, gx1, smem);
+    } else {
+        b -= n1;
+        const DenseFwdArgs& a = raae::args_from_ptr(&sa, &k->y);
+        dense_fwd_body<Q2>(a, b % gx2, b / gx2, gx2, smem);
     }
 }
 
@@ -451,11 +475,8 @@ __device__ __forceinline__ void stage_rows(float* Xs, int pitch, const float* x,
 // multipliers generated in the kernel, slopes requested before the statistic prologue.)
 // A first layer (K = 256 / 512 input points, no input transform) is split over blockIdx.y in slices of kw columns: more
 // workgroups for the launch-bound batches and a dW tile set of 8 tiles per wave (19.4 -> 12.0 us at 256 rows).
-template <int TPW, int KT4, bool ST = false>
-__global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs ka) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ DenseBwdArgs sa;
-    const DenseBwdArgs& a = raae::args_to_lds(&sa);       // (see dense_fwd_kernel)
+template <int TPW, int KT4, bool ST>
+__device__ __forceinline__ void dense_bwd_body(const DenseBwdArgs& a, float* smem) {
     const int st = ST ? a.storage : 0;
     const int k0 = blockIdx.y * a.kw, Kl = a.kw;      // this workgroup's input columns [k0, k0 + Kl)
     const int N16 = (a.N + 15) & ~15, K16 = (Kl + 15) & ~15;
@@ -669,6 +690,20 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs ka) {
         }
     }
 }
+template <int TPW, int KT4, bool ST = false>
+__global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs ka) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ DenseBwdArgs sa;
+    const DenseBwdArgs& a = raae::args_to_lds(&sa);       // (see dense_fwd_kernel)
+    dense_bwd_body<TPW, KT4, ST>(a, smem);
+}
+template <int TPW, int KT4, bool ST = false>
+__global__ __launch_bounds__(256) void dense_bwd_kernel_m(const DenseBwdArgs* table) {     // one trial per grid plane
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ DenseBwdArgs sa;
+    const DenseBwdArgs& a = raae::args_from_table(&sa, table);
+    dense_bwd_body<TPW, KT4, ST>(a, smem);
+}
 
 // Workgroups (= partial-statistic rows / gradient slabs) of a dense launch over B rows.  Every consumer reduces all
 // partial rows in its prologue, in every workgroup: rows x workgroups grows with the square of the grid, so large
@@ -719,8 +754,8 @@ static int prep_dense_fwd(const float* x, int B, int K, int in_kind, const float
 static void launch_dense_fwd(const DenseFwdArgs& a, dim3 grid, size_t lds, int kq, hipStream_t st) {
     const int rt = (int)grid.z;
     grid.z = 1;
-#define RAAE_FWD(KQ_, RT_) do { if (a.storage) hipLaunchKernelGGL((dense_fwd_kernel<KQ_, RT_, true>), grid, dim3(256), lds, st, a); \
-                               else hipLaunchKernelGGL((dense_fwd_kernel<KQ_, RT_, false>), grid, dim3(256), lds, st, a); } while (0)
+#define RAAE_FWD(KQ_, RT_) do { if (a.storage) raae::launch(dense_fwd_kernel<KQ_, RT_, true>, dense_fwd_kernel_m<KQ_, RT_, true>, grid, dim3(256), lds, st, a); \
+                               else raae::launch(dense_fwd_kernel<KQ_, RT_, false>, dense_fwd_kernel_m<KQ_, RT_, false>, grid, dim3(256), lds, st, a); } while (0)
     // bf16 storage (a.storage): the hidden layers of the dense networks (K <= 64 -> KQ 16; first layer KQ 64 / 128)
     if (rt == 4) {
         if (kq == 4) RAAE_FWD(4, 4);
@@ -794,8 +829,8 @@ extern "C" int raae_dense_fwd2(const raae_dense_fwd_t* p, const raae_dense_fwd_t
     g1.z = 1; g2.z = 1;
     // instances: the layer pairs of the 256-point dense networks (first layers 256 -> 64 beside 6 -> 64, then 64-wide
     // layers beside each other); anything else: two launches
-    if (!(p->storage | q->storage) && q1 == 64 && q2 == 4) hipLaunchKernelGGL((dense_fwd2_kernel<64, 4>), grid, dim3(256), lds, st, k);
-    else if (!(p->storage | q->storage) && q1 == 16 && q2 == 16) hipLaunchKernelGGL((dense_fwd2_kernel<16, 16>), grid, dim3(256), lds, st, k);
+    if (!(p->storage | q->storage) && q1 == 64 && q2 == 4) raae::launch(dense_fwd2_kernel<64, 4>, dense_fwd2_kernel_m<64, 4>, grid, dim3(256), lds, st, k);
+    else if (!(p->storage | q->storage) && q1 == 16 && q2 == 16) raae::launch(dense_fwd2_kernel<16, 16>, dense_fwd2_kernel_m<16, 16>, grid, dim3(256), lds, st, k);
     else {
         launch_dense_fwd(k.x, g1, l1, q1, st);
         launch_dense_fwd(k.y, g2, l2, q2, st);
@@ -876,8 +911,8 @@ extern "C" int raae_dense_bwd_s(const raae_dense_bwd_t* p, int* nslab, void* str
     dim3 grid(gx, K / a.kw), block(256);
     hipStream_t st = (hipStream_t)stream;
     const bool need_dx = p->dx != nullptr;
-#define RAAE_BWD(TPW_, KT4_) do { if (storage) hipLaunchKernelGGL((dense_bwd_kernel<TPW_, KT4_, true>), grid, block, lds, st, a); \
-                                 else hipLaunchKernelGGL((dense_bwd_kernel<TPW_, KT4_, false>), grid, block, lds, st, a); } while (0)
+#define RAAE_BWD(TPW_, KT4_) do { if (storage) raae::launch(dense_bwd_kernel<TPW_, KT4_, true>, dense_bwd_kernel_m<TPW_, KT4_, true>, grid, block, lds, st, a); \
+                                 else raae::launch(dense_bwd_kernel<TPW_, KT4_, false>, dense_bwd_kernel_m<TPW_, KT4_, false>, grid, block, lds, st, a); } while (0)
     if (tpw <= 1 && kt4 <= 1) RAAE_BWD(1, 1);
     else if (tpw <= 4 && kt4 <= 1) RAAE_BWD(4, 1);
     else if (tpw <= 8 && kt4 <= 2) RAAE_BWD(8, 2);               // a 128-column slice of a first layer

@@ -43,7 +43,7 @@ __device__ __forceinline__ double softplus_dd(double x) { return x > 0.0 ? x + l
 // 8192 x 64 x 64 per layer); below that the step is launch-bound and the VALU form keeps its thread mapping from
 // load to epilogue without the extra LDS round trip.
 template <bool MM>
-__global__ __launch_bounds__(256) void disc_fused_kernel(DiscArgs a) {
+__device__ __forceinline__ void disc_fused_body(const DiscArgs& a) {
     __shared__ float W1[DH * DNS], W2[DH * (DH + 1)], W3[DH], B1[DH], B2[DH], S1[DH], S2[DH];
     __shared__ float X[DT * DNS], Z1[DT * AP], A1[DT * AP], Z2[DT * AP], A2[DT * AP], G2[DT * AP], G1[DT * AP];
     __shared__ float DL[DT];
@@ -298,6 +298,13 @@ __global__ __launch_bounds__(256) void disc_fused_kernel(DiscArgs a) {
         }
     }
 }
+template <bool MM>
+__global__ __launch_bounds__(256) void disc_fused_kernel(DiscArgs a) { disc_fused_body<MM>(a); }
+template <bool MM>
+__global__ __launch_bounds__(256) void disc_fused_kernel_m(const DiscArgs* t) {     // one trial per grid plane (raae_common.h)
+    const DiscArgs a = t[blockIdx.z];
+    disc_fused_body<MM>(a);
+}
 
 }  // namespace
 
@@ -319,7 +326,7 @@ extern "C" int raae_disc_fused(const raae_disc_fused_t* in, int* nslab, void* st
     // from 2048 rows (real + fake) the 64 x 64 layers go through the matrix cores; RAAE_DISC_MFMA=0/1 forces a form
     static const int force = [] { const char* e = getenv("RAAE_DISC_MFMA"); return e ? atoi(e) : -1; }();
     const bool mm = force >= 0 ? force != 0 : (in->n_real + in->n_fake >= 2048);
-    if (mm) hipLaunchKernelGGL(disc_fused_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(disc_fused_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    if (mm) raae::launch(disc_fused_kernel<true>, disc_fused_kernel_m<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    else raae::launch(disc_fused_kernel<false>, disc_fused_kernel_m<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     RAAE_LAUNCH_RET();
 }

@@ -7,7 +7,8 @@ namespace {
 
 // ------------------------------------------------------------------ style BatchNorm
 // styles = BN(z) for z [B][C] (C = nstyle <= 64).  grid-stride over rows.
-__global__ __launch_bounds__(256) void style_bn_fwd_kernel(const float* z, int B, int C, raae_bn_t bn, float* out) {
+struct StyleFwdArgs { const float* z; int B; int C; raae_bn_t bn; float* out; };
+__device__ __forceinline__ void style_bn_fwd_body(const float* z, int B, int C, const raae_bn_t& bn, float* out) {
     __shared__ float s_mean[64], s_rstd[64];
     raae::bn_prologue(bn, C, s_mean, s_rstd, blockIdx.x == 0);
     const long n = (long)B * C;
@@ -17,10 +18,17 @@ __global__ __launch_bounds__(256) void style_bn_fwd_kernel(const float* z, int B
     }
 }
 
+__global__ __launch_bounds__(256) void style_bn_fwd_kernel(StyleFwdArgs a) { style_bn_fwd_body(a.z, a.B, a.C, a.bn, a.out); }
+__global__ __launch_bounds__(256) void style_bn_fwd_kernel_m(const StyleFwdArgs* t) {
+    const StyleFwdArgs a = t[blockIdx.z];
+    style_bn_fwd_body(a.z, a.B, a.C, a.bn, a.out);
+}
+
 // dz = rstd * (g - mean(g) - y * mean(g*y)), g = scale * dstyles.  Single workgroup: the
 // column sums over the whole batch are formed in fixed order (deterministic).
-__global__ __launch_bounds__(1024) void style_bn_bwd_kernel(const float* dy, const float* y, int B, int C,
-                                                            raae_bn_t bn, float scale, float* dz) {
+struct StyleBwdArgs { const float* dy; const float* y; int B; int C; raae_bn_t bn; float scale; float* dz; };
+__device__ __forceinline__ void style_bn_bwd_body(const float* dy, const float* y, int B, int C,
+                                                  const raae_bn_t& bn, float scale, float* dz) {
     __shared__ float s_mean[64], s_rstd[64];
     __shared__ double s_s[64], s_q[64];
     __shared__ double red[2][1024];
@@ -81,6 +89,12 @@ __global__ __launch_bounds__(1024) void style_bn_bwd_kernel(const float* dy, con
     }
 }
 
+__global__ __launch_bounds__(1024) void style_bn_bwd_kernel(StyleBwdArgs a) { style_bn_bwd_body(a.dy, a.y, a.B, a.C, a.bn, a.scale, a.dz); }
+__global__ __launch_bounds__(1024) void style_bn_bwd_kernel_m(const StyleBwdArgs* t) {
+    const StyleBwdArgs a = t[blockIdx.z];
+    style_bn_bwd_body(a.dy, a.y, a.B, a.C, a.bn, a.scale, a.dz);
+}
+
 // ------------------------------------------------------------------ rank ("Kendall") loss
 // functions.py:37-79.  One pass over the B^2 pairs; per (i,k): g+ = sum_{j: p>0} s, g- = sum_{j: p<0} s;
 // per k: n+, n-, S+ = sum_{p>0} p, S- = sum_{p<0} p.  Thread owns one row i for ALL k (n_aux <= 16)
@@ -103,10 +117,12 @@ struct RankWork {   // per-workgroup partial: [k]{n_pos, n_neg} ints and {S_pos,
 // 171 row groups x 6 column blocks = 1026 workgroups for the 256 CUs instead of 171.
 // Rows are [row0, row0 + nrows) of arrays with n_all rows, columns ALL n_all rows: nrows == n_all is the
 // reference's loss over one batch; nrows < n_all is one rank's share of the global pairs under data parallelism.
+struct RankPairsArgs { const float* d; int ldd; const float* z; int ldz; int n_all; int row0; int nrows; int nj; int jchunk;
+                       RankWork* part; float* gpos; float* gneg; };
 template <int KA, int R>
-__global__ __launch_bounds__(256) void rank_pairs_kernel(const float* d, int ldd, const float* z, int ldz, int n_all,
-                                                         int row0, int nrows, int nj, int jchunk,
-                                                         RankWork* part, float* gpos, float* gneg) {
+__device__ __forceinline__ void rank_pairs_body(const float* d, int ldd, const float* z, int ldz, int n_all,
+                                                int row0, int nrows, int nj, int jchunk,
+                                                RankWork* part, float* gpos, float* gneg) {
     constexpr int IPB = 32 / KA;            // (row, k) slots per block = IPB * KA <= 32
     __shared__ float sd[RANK_TJ * KA], sz[RANK_TJ * KA];
     __shared__ double red_s[2][32];
@@ -188,15 +204,27 @@ __global__ __launch_bounds__(256) void rank_pairs_kernel(const float* d, int ldd
     }
 }
 
+template <int KA, int R>
+__global__ __launch_bounds__(256) void rank_pairs_kernel(RankPairsArgs a) {
+    rank_pairs_body<KA, R>(a.d, a.ldd, a.z, a.ldz, a.n_all, a.row0, a.nrows, a.nj, a.jchunk, a.part, a.gpos, a.gneg);
+}
+template <int KA, int R>
+__global__ __launch_bounds__(256) void rank_pairs_kernel_m(const RankPairsArgs* t) {
+    const RankPairsArgs a = t[blockIdx.z];
+    rank_pairs_body<KA, R>(a.d, a.ldd, a.z, a.ldz, a.n_all, a.row0, a.nrows, a.nj, a.jchunk, a.part, a.gpos, a.gneg);
+}
+
 // finalize: c_k, loss, dz[i][k] = -(2/norm)(c_k g+ + g-).  Every workgroup re-derives c_k from the
 // partials (16 slices per descriptor, fixed order), then grid-strides over dz.
 // `totals` != NULL: the per-descriptor totals {n+, n-, S+, S-} [4][16] doubles are given (summed over the ranks of a
 // data-parallel run: global pairs) and `part` is not read.  norm = (n_all^2 - n_all) * KA; `scale` multiplies dz
 // (the number of ranks, whose gradients the engine AVERAGES).
-__global__ __launch_bounds__(256) void rank_finalize_kernel(const RankWork* part, int nparts, const double* totals, int n_all,
-                                                            int nrows, int nj, int KA, int activate, float scale,
-                                                            const float* gpos, const float* gneg, float* loss,
-                                                            float* dz, int ldz) {
+struct RankFinArgs { const RankWork* part; int nparts; const double* totals; int n_all; int nrows; int nj; int KA; int activate;
+                     float scale; const float* gpos; const float* gneg; float* loss; float* dz; int ldz; };
+__device__ __forceinline__ void rank_finalize_body(const RankWork* part, int nparts, const double* totals, int n_all,
+                                                   int nrows, int nj, int KA, int activate, float scale,
+                                                   const float* gpos, const float* gneg, float* loss,
+                                                   float* dz, int ldz) {
     __shared__ float s_c[RANK_MAXK];
     __shared__ double s_loss[RANK_MAXK];
     __shared__ double r_s[2][256];
@@ -258,6 +286,14 @@ __global__ __launch_bounds__(256) void rank_finalize_kernel(const RankWork* part
             dz[idx] = v;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void rank_finalize_kernel(RankFinArgs a) {
+    rank_finalize_body(a.part, a.nparts, a.totals, a.n_all, a.nrows, a.nj, a.KA, a.activate, a.scale, a.gpos, a.gneg, a.loss, a.dz, a.ldz);
+}
+__global__ __launch_bounds__(256) void rank_finalize_kernel_m(const RankFinArgs* t) {
+    const RankFinArgs a = t[blockIdx.z];
+    rank_finalize_body(a.part, a.nparts, a.totals, a.n_all, a.nrows, a.nj, a.KA, a.activate, a.scale, a.gpos, a.gneg, a.loss, a.dz, a.ldz);
 }
 
 // per-descriptor totals {n+, n-, S+, S-} of this rank's pairs as [4][16] doubles (fixed order): what a data-parallel
@@ -323,8 +359,9 @@ static LossFin make_fin(const raae_loss_fin_t* fin) {
     return f;
 }
 
-__global__ __launch_bounds__(256) void recon_kernel(const float* x, const float* y, int B, int L, int scale,
-                                                    double* partial, float* dy, LossFin fin) {
+struct ReconArgs { const float* x; const float* y; int B; int L; int scale; double* partial; float* dy; LossFin fin; };
+__device__ __forceinline__ void recon_body(const float* x, const float* y, int B, int L, int scale,
+                                           double* partial, float* dy, const LossFin& fin) {
     __shared__ double shd[16];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double acc = 0.0;
@@ -358,6 +395,12 @@ __global__ __launch_bounds__(256) void recon_kernel(const float* x, const float*
     loss_fin_last_block(fin, partial);
 }
 
+__global__ __launch_bounds__(256) void recon_kernel(ReconArgs a) { recon_body(a.x, a.y, a.B, a.L, a.scale, a.partial, a.dy, a.fin); }
+__global__ __launch_bounds__(256) void recon_kernel_m(const ReconArgs* t) {
+    const ReconArgs a = t[blockIdx.z];
+    recon_body(a.x, a.y, a.B, a.L, a.scale, a.partial, a.dy, a.fin);
+}
+
 // ------------------------------------------------------------------ smoothness loss
 // functions.py:194-212 + GaussianSmoothing (model.py:177-229).  One wave per row, row in LDS.
 // loss = mean((x - Gx)^2); dL/dx = (2/N) (e - G^T e), e = x - Gx, G = replicate-pad Gaussian.
@@ -367,8 +410,9 @@ struct Taps { float w[SM_MAXT]; int n; };
 // NT > 0: the tap count at compile time (17 for the reference's smoothing): the tap loops unroll and the weights
 // stay in scalar registers -- with a run-time count every tap was a scalar load from the kernarg segment with its
 // own wait (15.7 us for 256 rows; NT = 0 keeps that generic form).
+struct SmoothArgs { const float* x; int B; int L; Taps tp; double* partial; float* dx; LossFin fin; };
 template <int NT>
-__global__ __launch_bounds__(256) void smooth_kernel(const float* x, int B, int L, Taps tp, double* partial, float* dx, LossFin fin) {
+__device__ __forceinline__ void smooth_body(const float* x, int B, int L, const Taps& tp, double* partial, float* dx, const LossFin& fin) {
     const int ntap = NT > 0 ? NT : tp.n;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [4 waves][2][L]
     __shared__ double shd[16];
@@ -426,8 +470,17 @@ __global__ __launch_bounds__(256) void smooth_kernel(const float* x, int B, int 
     loss_fin_last_block(fin, partial);
 }
 
+template <int NT>
+__global__ __launch_bounds__(256) void smooth_kernel(SmoothArgs a) { smooth_body<NT>(a.x, a.B, a.L, a.tp, a.partial, a.dx, a.fin); }
+template <int NT>
+__global__ __launch_bounds__(256) void smooth_kernel_m(const SmoothArgs* t) {
+    const SmoothArgs a = t[blockIdx.z];
+    smooth_body<NT>(a.x, a.B, a.L, a.tp, a.partial, a.dx, a.fin);
+}
+
 // ------------------------------------------------------------------ MSE (mutual-info loss)
-__global__ __launch_bounds__(256) void mse_kernel(const float* a, const float* b, long n, double* partial, float* da, LossFin fin) {
+struct MseArgs { const float* a; const float* b; long n; double* partial; float* da; LossFin fin; };
+__device__ __forceinline__ void mse_body(const float* a, const float* b, long n, double* partial, float* da, const LossFin& fin) {
     __shared__ double shd[16];
     double acc = 0.0;
     const float inv = 1.f / (float)n;
@@ -439,6 +492,12 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* a, const float* b
     const double t = raae::block_sum(acc, shd);
     if (threadIdx.x == 0) partial[blockIdx.x] = t / (double)n;
     loss_fin_last_block(fin, partial);
+}
+
+__global__ __launch_bounds__(256) void mse_kernel(MseArgs a) { mse_body(a.a, a.b, a.n, a.partial, a.da, a.fin); }
+__global__ __launch_bounds__(256) void mse_kernel_m(const MseArgs* t) {
+    const MseArgs a = t[blockIdx.z];
+    mse_body(a.a, a.b, a.n, a.partial, a.da, a.fin);
 }
 
 // ------------------------------------------------------------------ BCE-with-logits pair
@@ -530,16 +589,16 @@ int grid_for(long n, int per_block, int cap) {
 
 extern "C" int raae_style_bn_fwd(const float* z, int B, int C, const raae_bn_t* bn, float* styles, void* stream) {
     RAAE_CHECK_ARG(z && bn && styles && B > 0 && C > 0 && C <= 64 && bn->nparts <= RAAE_MAX_PARTS);
-    hipLaunchKernelGGL(style_bn_fwd_kernel, dim3(grid_for((long)B * C, 256, 256)), dim3(256), 0, (hipStream_t)stream,
-                       z, B, C, *bn, styles);
+    const StyleFwdArgs a = {z, B, C, *bn, styles};
+    raae::launch(style_bn_fwd_kernel, style_bn_fwd_kernel_m, dim3(grid_for((long)B * C, 256, 256)), dim3(256), 0, (hipStream_t)stream, a);
     RAAE_LAUNCH_RET();
 }
 
 extern "C" int raae_style_bn_bwd(const float* dstyles, const float* styles, int B, int C, const raae_bn_t* bn,
                                  float scale, float* dz, void* stream) {
     RAAE_CHECK_ARG(dstyles && styles && bn && dz && B > 0 && C > 0 && C <= 64 && bn->nparts <= RAAE_MAX_PARTS);
-    hipLaunchKernelGGL(style_bn_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dstyles, styles, B, C, *bn,
-                       scale, dz);
+    const StyleBwdArgs a = {dstyles, styles, B, C, *bn, scale, dz};
+    raae::launch(style_bn_bwd_kernel, style_bn_bwd_kernel_m, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
     RAAE_LAUNCH_RET();
 }
 
@@ -585,9 +644,10 @@ static int rank_pairs_launch(const float* d, int ldd, const float* z, int ldz, i
     RankWork* part = (RankWork*)work;
     gpos = (float*)((char*)work + rank_part_bytes());
     gneg = gpos + (size_t)RANK_MAXNJ * nrows * n_aux;
+    const RankPairsArgs pa = {d, ldd, z, ldz, n_all, row0, nrows, g.nj, g.jchunk, part, gpos, gneg};
 #define RANK_CASE(KA) case KA: \
-        if (g.R == 1) hipLaunchKernelGGL((rank_pairs_kernel<KA, 1>), dim3(g.nwg), dim3(256), 0, st, d, ldd, z, ldz, n_all, row0, nrows, g.nj, g.jchunk, part, gpos, gneg); \
-        else hipLaunchKernelGGL((rank_pairs_kernel<KA, 4>), dim3(g.nwg), dim3(256), 0, st, d, ldd, z, ldz, n_all, row0, nrows, g.nj, g.jchunk, part, gpos, gneg); \
+        if (g.R == 1) raae::launch(rank_pairs_kernel<KA, 1>, rank_pairs_kernel_m<KA, 1>, dim3(g.nwg), dim3(256), 0, st, pa); \
+        else raae::launch(rank_pairs_kernel<KA, 4>, rank_pairs_kernel_m<KA, 4>, dim3(g.nwg), dim3(256), 0, st, pa); \
         break;
     switch (n_aux) {
         RANK_CASE(1) RANK_CASE(2) RANK_CASE(3) RANK_CASE(4) RANK_CASE(5) RANK_CASE(6) RANK_CASE(7) RANK_CASE(8)
@@ -607,8 +667,8 @@ extern "C" int raae_rank_loss_fwd_bwd(const float* d, int ldd, const float* z, i
     const int rc = rank_pairs_launch(d, ldd, z, ldz, B, 0, B, n_aux, work, g, gpos, gneg, st);
     if (rc) return rc;
     const int gf = dz ? grid_for((long)B * ldz, 256, 256) : 1;
-    hipLaunchKernelGGL(rank_finalize_kernel, dim3(gf), dim3(256), 0, st, (const RankWork*)work, g.nwg, (const double*)nullptr, B,
-                       B, g.nj, n_aux, activate, 1.f, gpos, gneg, loss, dz, ldz);
+    const RankFinArgs fa = {(const RankWork*)work, g.nwg, (const double*)nullptr, B, B, g.nj, n_aux, activate, 1.f, gpos, gneg, loss, dz, ldz};
+    raae::launch(rank_finalize_kernel, rank_finalize_kernel_m, dim3(gf), dim3(256), 0, st, fa);
     RAAE_LAUNCH_RET();
 }
 
@@ -636,8 +696,8 @@ extern "C" int raae_rank_rows_finish(const double* totals, int n_all, int nrows,
     float* gpos = (float*)((char*)work + rank_part_bytes());
     float* gneg = gpos + (size_t)RANK_MAXNJ * nrows * n_aux;
     const int gf = dz ? grid_for((long)nrows * ldz, 256, 256) : 1;
-    hipLaunchKernelGGL(rank_finalize_kernel, dim3(gf), dim3(256), 0, (hipStream_t)stream, (const RankWork*)nullptr, 0, totals,
-                       n_all, nrows, g.nj, n_aux, activate, scale, gpos, gneg, loss, dz, ldz);
+    const RankFinArgs fa = {(const RankWork*)nullptr, 0, totals, n_all, nrows, g.nj, n_aux, activate, scale, gpos, gneg, loss, dz, ldz};
+    raae::launch(rank_finalize_kernel, rank_finalize_kernel_m, dim3(gf), dim3(256), 0, (hipStream_t)stream, fa);
     RAAE_LAUNCH_RET();
 }
 
@@ -646,7 +706,8 @@ extern "C" int raae_recon_loss_fwd_bwd(const float* spec_in, const float* spec_o
     RAAE_CHECK_ARG(spec_in && spec_out && partial && B > 0 && L > 0 && (!fin || !fin->ticket || (fin->out && fin->slot >= 0)));
     const int g = grid_for(B, 4, RAAE_MAX_PARTS);
     if (nparts) *nparts = g;
-    hipLaunchKernelGGL(recon_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, spec_in, spec_out, B, L, scale, partial, dout, make_fin(fin));
+    const ReconArgs a = {spec_in, spec_out, B, L, scale, partial, dout, make_fin(fin)};
+    raae::launch(recon_kernel, recon_kernel_m, dim3(g), dim3(256), 0, (hipStream_t)stream, a);
     RAAE_LAUNCH_RET();
 }
 
@@ -657,10 +718,11 @@ extern "C" int raae_smooth_loss_fwd_bwd(const float* x, int B, int L, const floa
     for (int i = 0; i < ntaps; ++i) tp.w[i] = taps[i];   // `taps` is a HOST pointer (17 floats)
     const int g = grid_for(B, 4, RAAE_MAX_PARTS);
     if (nparts) *nparts = g;
+    const SmoothArgs a = {x, B, L, tp, partial, dx, make_fin(fin)};
     if (ntaps == 17)
-        hipLaunchKernelGGL(smooth_kernel<17>, dim3(g), dim3(256), sizeof(float) * 8 * (size_t)L, (hipStream_t)stream, x, B, L, tp, partial, dx, make_fin(fin));
+        raae::launch(smooth_kernel<17>, smooth_kernel_m<17>, dim3(g), dim3(256), sizeof(float) * 8 * (size_t)L, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(smooth_kernel<0>, dim3(g), dim3(256), sizeof(float) * 8 * (size_t)L, (hipStream_t)stream, x, B, L, tp, partial, dx, make_fin(fin));
+        raae::launch(smooth_kernel<0>, smooth_kernel_m<0>, dim3(g), dim3(256), sizeof(float) * 8 * (size_t)L, (hipStream_t)stream, a);
     RAAE_LAUNCH_RET();
 }
 
@@ -669,7 +731,8 @@ extern "C" int raae_mse_fwd_bwd(const float* a, const float* b, long n, double* 
     RAAE_CHECK_ARG(a && b && partial && n > 0 && (!fin || !fin->ticket || (fin->out && fin->slot >= 0)));
     const int g = grid_for(n, 1024, RAAE_MAX_PARTS);
     if (nparts) *nparts = g;
-    hipLaunchKernelGGL(mse_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, a, b, n, partial, da, make_fin(fin));
+    const MseArgs ma = {a, b, n, partial, da, make_fin(fin)};
+    raae::launch(mse_kernel, mse_kernel_m, dim3(g), dim3(256), 0, (hipStream_t)stream, ma);
     RAAE_LAUNCH_RET();
 }
 

@@ -10,9 +10,11 @@ namespace {
 // operation order mirrored in fp32; scalars formed in double like Python floats.
 // Gradient of element i = fixed-order sum of seg_nslab[i/64] slabs; 0 slabs => parameter is
 // skipped (the reference skips params whose .grad is None, trainer.py:318-321).
-__global__ __launch_bounds__(256) void adam_kernel(float* p, float* m, float* v, const float* g_slabs, long slab_stride,
-                                                   const unsigned short* seg_nslab, long n, const double* hyper,
-                                                   const int* step, int decoupled) {
+struct AdamArgs { float* p; float* m; float* v; const float* g_slabs; long slab_stride; const unsigned short* seg_nslab;
+                  long n; const double* hyper; const int* step; int decoupled; };
+__device__ __forceinline__ void adam_body(float* p, float* m, float* v, const float* g_slabs, long slab_stride,
+                                          const unsigned short* seg_nslab, long n, const double* hyper,
+                                          const int* step, int decoupled) {
     __shared__ float s_sc[8];
     if (threadIdx.x == 0) {
         const double lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
@@ -56,10 +58,18 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, float* m, float* v,
     }
 }
 
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+    adam_body(a.p, a.m, a.v, a.g_slabs, a.slab_stride, a.seg_nslab, a.n, a.hyper, a.step, a.decoupled);
+}
+__global__ __launch_bounds__(256) void adam_kernel_m(const AdamArgs* t) {
+    const AdamArgs a = t[blockIdx.z];
+    adam_body(a.p, a.m, a.v, a.g_slabs, a.slab_stride, a.seg_nslab, a.n, a.hyper, a.step, a.decoupled);
+}
+
 // Same update with the slabs of an element spread over 8 lanes: for ranges whose tensors have many slabs.
-__global__ __launch_bounds__(256) void adam_wide_kernel(float* p, float* m, float* v, const float* g_slabs, long slab_stride,
-                                                   const unsigned short* seg_nslab, long n, const double* hyper,
-                                                   const int* step, int decoupled) {
+__device__ __forceinline__ void adam_wide_body(float* p, float* m, float* v, const float* g_slabs, long slab_stride,
+                                               const unsigned short* seg_nslab, long n, const double* hyper,
+                                               const int* step, int decoupled) {
     __shared__ float s_sc[8];
     if (threadIdx.x == 0) {
         const double lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
@@ -111,6 +121,14 @@ __global__ __launch_bounds__(256) void adam_wide_kernel(float* p, float* m, floa
         pv = pv + (nstep * mv) / denom;
         p[i] = pv; m[i] = mv; v[i] = vv;
     }
+}
+
+__global__ __launch_bounds__(256) void adam_wide_kernel(AdamArgs a) {
+    adam_wide_body(a.p, a.m, a.v, a.g_slabs, a.slab_stride, a.seg_nslab, a.n, a.hyper, a.step, a.decoupled);
+}
+__global__ __launch_bounds__(256) void adam_wide_kernel_m(const AdamArgs* t) {
+    const AdamArgs a = t[blockIdx.z];
+    adam_wide_body(a.p, a.m, a.v, a.g_slabs, a.slab_stride, a.seg_nslab, a.n, a.hyper, a.step, a.decoupled);
 }
 
 __global__ void tick_kernel(int* steps, int n, unsigned mask, unsigned long long* rng_counter, int* cursor,
@@ -210,7 +228,7 @@ struct StepBeginArgs {
     float* spec_out; float* aux_out;
     float* tape; const int* seg_desc; const float* seg_scale; int nseg; long total;     // nseg == 0: no fill
 };
-__global__ __launch_bounds__(256) void step_begin_kernel(StepBeginArgs a) {
+__device__ __forceinline__ void step_begin_body(const StepBeginArgs& a) {
     // Thread 0 reads the old counters, hands them to the workgroup through LDS and only then takes the workgroup's
     // ticket -- at the START (the value comes back while the workgroup works): whoever draws the last one knows that
     // every workgroup has READ the counters (the LDS stores need the loaded values, and precede the ticket in program
@@ -286,6 +304,11 @@ __global__ __launch_bounds__(256) void step_begin_kernel(StepBeginArgs a) {
         *a.ticket = 0u;
     }
 }
+__global__ __launch_bounds__(256) void step_begin_kernel(StepBeginArgs a) { step_begin_body(a); }
+__global__ __launch_bounds__(256) void step_begin_kernel_m(const StepBeginArgs* t) {
+    const StepBeginArgs a = t[blockIdx.z];
+    step_begin_body(a);
+}
 
 }  // namespace
 
@@ -293,16 +316,15 @@ extern "C" int raae_adam_step(float* p, float* m, float* v, const float* g_slabs
                               const unsigned short* seg_nslab, long n, const double* hyper, const int* step,
                               int decoupled, int max_nslab, void* stream) {
     RAAE_CHECK_ARG(p && m && v && g_slabs && seg_nslab && hyper && step && n > 0 && (n % 64) == 0 && max_nslab >= 0);
+    const AdamArgs a = {p, m, v, g_slabs, slab_stride, seg_nslab, n, hyper, step, decoupled};
     if (max_nslab > 16) {
         long g = (n + 31) / 32;                 // 32 elements per workgroup (8 lanes per element)
         if (g > 4096) g = 4096;
-        hipLaunchKernelGGL(adam_wide_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, p, m, v, g_slabs, slab_stride,
-                           seg_nslab, n, hyper, step, decoupled);
+        raae::launch(adam_wide_kernel, adam_wide_kernel_m, dim3((int)g), dim3(256), 0, (hipStream_t)stream, a);
     } else {
         long g = (n + 255) / 256;               // one element per thread
         if (g > 4096) g = 4096;
-        hipLaunchKernelGGL(adam_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, p, m, v, g_slabs, slab_stride,
-                           seg_nslab, n, hyper, step, decoupled);
+        raae::launch(adam_kernel, adam_kernel_m, dim3((int)g), dim3(256), 0, (hipStream_t)stream, a);
     }
     RAAE_LAUNCH_RET();
 }
@@ -341,7 +363,7 @@ extern "C" int raae_step_begin(const raae_step_begin_t* p, void* stream) {
     long g = (work + 4095) / 4096;          // ~16 quads per thread ...
     if (g > 1024) g = 1024;                 // ... up to 1024 workgroups (their tickets, ~40 us, come back during ~45 us of fill at 4096 rows)
     if (g < 64) g = 64;
-    hipLaunchKernelGGL(step_begin_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, a);
+    raae::launch(step_begin_kernel, step_begin_kernel_m, dim3((int)g), dim3(256), 0, (hipStream_t)stream, a);
     RAAE_LAUNCH_RET();
 }
 
@@ -463,4 +485,88 @@ extern "C" int raae_slab_reduce(const float* g_slabs, long slab_stride, const un
                            seg_nslab, n, out);
     }
     RAAE_LAUNCH_RET();
+}
+
+
+// ---------------------------------------------------------------- batched launches over trials (raae_common.h)
+#include <vector>
+namespace {
+struct LaunchRec { const void* fn; dim3 grid, block; unsigned lds, nbytes; unsigned char args[1536]; };
+struct Recording { std::vector<LaunchRec> recs; bool bad = false; };
+thread_local Recording* g_recording = nullptr;
+struct MultiProgram { std::vector<LaunchRec> recs; std::vector<size_t> off; unsigned char* table = nullptr; int T = 0; };
+}  // namespace
+void raae::record_launch(const void* multi_fn, dim3 grid, dim3 block, size_t lds, const void* args, size_t nbytes) {
+    Recording* r = g_recording;
+    if (!r) return;
+    LaunchRec rec;
+    if (nbytes > sizeof(rec.args) || grid.z != 1) { r->bad = true; return; }
+    rec.fn = multi_fn; rec.grid = grid; rec.block = block; rec.lds = (unsigned)lds; rec.nbytes = (unsigned)nbytes;
+    memcpy(rec.args, args, nbytes);
+    r->recs.push_back(rec);
+}
+extern "C" int raae_record_begin(void) {
+    if (g_recording) return RAAE_EINVAL;
+    g_recording = new Recording();
+    return 0;
+}
+extern "C" int raae_record_end(void** handle, int* n_launches) {
+    RAAE_CHECK_ARG(handle && g_recording);
+    Recording* r = g_recording;
+    g_recording = nullptr;
+    if (r->bad) { delete r; return RAAE_EINVAL; }
+    if (n_launches) *n_launches = (int)r->recs.size();
+    *handle = r;
+    return 0;
+}
+extern "C" int raae_record_free(void* handle) { delete (Recording*)handle; return 0; }
+extern "C" int raae_multi_build(void* const* handles, int T, void** program) {
+    RAAE_CHECK_ARG(handles && program && T >= 1 && T <= 64);
+    const Recording* r0 = (const Recording*)handles[0];
+    RAAE_CHECK_ARG(r0 && !r0->recs.empty());
+    MultiProgram* mp = new MultiProgram();
+    mp->T = T; mp->recs = r0->recs;
+    size_t total = 0;
+    for (size_t i = 0; i < r0->recs.size(); ++i) {
+        mp->off.push_back(total);
+        total += ((size_t)T * r0->recs[i].nbytes + 255) & ~(size_t)255;
+    }
+    std::vector<unsigned char> host(total, 0);
+    for (int t = 0; t < T; ++t) {
+        const Recording* r = (const Recording*)handles[t];
+        if (!r || r->recs.size() != r0->recs.size()) { delete mp; return RAAE_EINVAL; }
+        for (size_t i = 0; i < r->recs.size(); ++i) {
+            const LaunchRec &a = r0->recs[i], &b = r->recs[i];
+            // the trials must be structurally identical: same kernel instance, geometry and LDS at every launch
+            if (a.fn != b.fn || a.grid.x != b.grid.x || a.grid.y != b.grid.y || a.block.x != b.block.x || a.lds != b.lds ||
+                a.nbytes != b.nbytes) { delete mp; return RAAE_EINVAL; }
+            memcpy(host.data() + mp->off[i] + (size_t)t * a.nbytes, b.args, a.nbytes);
+        }
+    }
+    hipError_t e = hipMalloc((void**)&mp->table, total);
+    if (e != hipSuccess) { delete mp; return (int)e; }
+    e = hipMemcpy(mp->table, host.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(mp->table); delete mp; return (int)e; }
+    *program = mp;
+    return 0;
+}
+extern "C" int raae_multi_launch(void* program, void* stream) {
+    RAAE_CHECK_ARG(program);
+    MultiProgram* mp = (MultiProgram*)program;
+    for (size_t i = 0; i < mp->recs.size(); ++i) {
+        const LaunchRec& r = mp->recs[i];
+        void* tptr = mp->table + mp->off[i];
+        void* params[1] = {&tptr};
+        const hipError_t e = hipLaunchKernel(r.fn, dim3(r.grid.x, r.grid.y, mp->T), r.block, params, r.lds, (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+extern "C" int raae_multi_count(void* program) { return program ? (int)((MultiProgram*)program)->recs.size() : 0; }
+extern "C" int raae_multi_free(void* program) {
+    if (!program) return 0;
+    MultiProgram* mp = (MultiProgram*)program;
+    if (mp->table) (void)hipFree(mp->table);
+    delete mp;
+    return 0;
 }

@@ -476,7 +476,7 @@ class StepPlan:
 
 class StepEngine:
     def __init__(self, encoder, decoder, discriminator, cfg, device, rng_mode="philox", seed=0, use_graph=True,
-                 world_size=1, rank=0, process_group=None):
+                 world_size=1, rank=0, process_group=None, stream=None):
         """``world_size > 1``: synchronous data parallelism, one process per GPU over RCCL.  Every rank
         holds the same parameters, steps its own shard of the global batch (per-replica BatchNorm
         statistics, rank loss over the local pairs) and the five per-phase gradient arenas are averaged
@@ -487,7 +487,8 @@ class StepEngine:
         self.cfg, self.device = dict(cfg), device
         self.world_size, self.rank, self.pg = int(world_size), int(rank), process_group
         self.graph_ar = None
-        self.stream = torch.cuda.Stream(device=device)      # hipGraph capture is illegal on the null stream
+        # (`stream`: engines of a TrialBatch share one stream -- their batched step is one launch sequence on it)
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=device)      # hipGraph capture is illegal on the null stream
         self.stream.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(self.stream):
             self._init(encoder, decoder, discriminator, cfg, device, rng_mode, seed, use_graph)
@@ -1050,9 +1051,8 @@ class StepEngine:
             self._adam(P, "smoothness", self._slab_notes)
         self._slab_notes = None
 
-    @_on_stream
-    def step(self, b, smooth=True):
-        """Run one training step on the next ``b`` rows of the epoch permutation."""
+    def _pre_step(self, b, smooth):
+        """Host side of a step before anything is launched: plan, bounds check, device cursor priming, host tape."""
         if b < 2:
             # a one-row last batch: the reference's training-mode BatchNorm1d(nstyle) raises exactly this
             raise ValueError("Expected more than 1 value per channel when training, got input size "
@@ -1071,6 +1071,12 @@ class StepEngine:
             P.tape.draws, saved = (P.tape.draws if smooth else P.tape.draws[:P.n_draws_no_smooth]), P.tape.draws
             P.tape.fill_host()
             P.tape.draws = saved
+        return P
+
+    @_on_stream
+    def step(self, b, smooth=True):
+        """Run one training step on the next ``b`` rows of the epoch permutation."""
+        P = self._pre_step(b, smooth)
         key = bool(smooth)
         if key not in P.graphs:
             # first call: eager emission (records slab counts, sets kernel attributes) ...

@@ -67,7 +67,7 @@ class Trainer:
 
     def __init__(self, encoder, decoder, discriminator, device, train_loader, val_loader, verbose=True,
                  work_dir='.', tb_logdir="runs", config_parameters=Parameters({}),
-                 logger=logging.getLogger("training"), loss_logger=logging.getLogger("losses")):
+                 logger=logging.getLogger("training"), loss_logger=logging.getLogger("losses"), engine_stream=None):
         self.logger, self.loss_logger = logger, loss_logger
         self.device = device
         self.encoder, self.decoder, self.discriminator = encoder, decoder, discriminator
@@ -95,7 +95,7 @@ class Trainer:
         self.engine = StepEngine(encoder, decoder, discriminator, cfg, device,
                                  rng_mode=cfg.get("rng_mode", "philox"), seed=seed,
                                  use_graph=cfg.get("use_graph", True), world_size=self.world, rank=self.rank,
-                                 process_group=self.pg)
+                                 process_group=self.pg, stream=engine_stream)
         ds = train_loader.dataset
         if ds.aux is None:
             raise ValueError("n_aux: 0 is not reachable in the reference (SURVEY.md finding 4)")
@@ -147,7 +147,16 @@ class Trainer:
     def train(self, callback=None):
         eng = self.engine
         try:
-            return self._train_epochs(callback)
+            # _train_epochs is a generator that hands every training step out as ("step", rows, smooth): here the
+            # trial's own engine runs it; train_trials_batched runs the same request of T trials as ONE launch sequence
+            gen = self._train_epochs(callback)
+            try:
+                req = next(gen)
+                while True:
+                    eng.step(req[1], smooth=req[2])
+                    req = next(gen)
+            except StopIteration as done:
+                return done.value
         finally:
             # a worker process runs several trials: the next one must be able to collect this one's objects -- also when
             # the run ends in an exception (the SIGALRM "Training Overtime!", a caller's try/except around train())
@@ -202,7 +211,7 @@ class Trainer:
                 if self.world > 1 and rows != prev_rows:      # first step of the epoch, and again at the tail
                     eng.seek(off + self.rank * rows, global_rows)
                 prev_rows = rows
-                eng.step(rows, smooth=smooth)
+                yield ("step", rows, smooth)
             if epoch == 1 and self.freeze_gc and not self._gc_frozen:
                 # plans, captured graphs and modules are long-lived: out of the cyclic collector's way (a full
                 # collection in the middle of an epoch stalls the host for longer than the queue of launched steps lasts)
@@ -257,9 +266,10 @@ class Trainer:
     @classmethod
     def from_data(cls, csv_fn, igpu=0, verbose=True, work_dir='.', train_ratio=0.7, validation_ratio=0.15,
                   test_ratio=0.15, config_parameters=Parameters({}), logger=logging.getLogger("from_data"),
-                  loss_logger=logging.getLogger("losses"), arrays=None, host_rng=None):
+                  loss_logger=logging.getLogger("losses"), arrays=None, host_rng=None, engine_stream=None):
         """``host_rng`` (build-only): a private ``torch.Generator`` for this trial's epoch permutations and device-RNG
-        seed instead of the global CPU generator (several trials in one process)."""
+        seed instead of the global CPU generator (several trials in one process).  ``engine_stream``: the HIP stream
+        the engine works on (the trials of a ``TrialBatch`` share one)."""
         p = config_parameters
         assert p.ae_form in AE_CLS_DICT
         dl_train, dl_val, _ = get_dataloaders(csv_fn, p.batch_size, (train_ratio, validation_ratio, test_ratio),
@@ -281,4 +291,42 @@ class Trainer:
         discriminator = DiscriminatorFC(nstyle=p.nstyle, dropout_rate=p.dis_dropout_rate, noise=p.dis_noise,
                                         layers=p.FC_discriminator_layers)
         return cls(encoder, decoder, discriminator, device, dl_train, dl_val, verbose=verbose, work_dir=work_dir,
-                   config_parameters=p, logger=logger, loss_logger=loss_logger)
+                   config_parameters=p, logger=logger, loss_logger=loss_logger, engine_stream=engine_stream)
+
+
+def train_trials_batched(trainers, callbacks=None):
+    """``train()`` of T trainers of ONE configuration in lockstep, every training step of the T trials as one launch
+    sequence with ``gridDim.z = T`` (``rankaae_amd.trial_batch.TrialBatch``; dense networks).  Everything around the
+    step -- epoch permutation, validation, metrics, schedulers, checkpoints, log rows -- is each trainer's own code,
+    run trial after trial between the steps.  Returns the trials' metrics lists.  A trial that asks to stop
+    (``request_stop``) ends the whole batch with the reference's exception: the trials advance together."""
+    from .trial_batch import TrialBatch
+    callbacks = callbacks or [None] * len(trainers)
+    batch = TrialBatch([t.engine for t in trainers])
+    gens = [t._train_epochs(cb) for t, cb in zip(trainers, callbacks)]
+    results = [None] * len(trainers)
+    try:
+        live = True
+        while live:
+            reqs = []
+            for i, g in enumerate(gens):
+                try:
+                    reqs.append(next(g))
+                except StopIteration as done:
+                    results[i] = done.value
+                    reqs.append(None)
+            if all(r is None for r in reqs):
+                break
+            if any(r is None for r in reqs) or any(r != reqs[0] for r in reqs):
+                raise RuntimeError(f"the trials of a batch left lockstep: {reqs}")
+            batch.step(reqs[0][1], smooth=reqs[0][2])
+        return results
+    finally:
+        for g in gens:
+            g.close()
+        for t in trainers:
+            if t._gc_frozen:
+                gc.unfreeze()
+                t._gc_frozen = False
+            t.engine.close()
+        batch.release()

@@ -878,3 +878,62 @@ def test_bf16_storage_mode_fc_512_aux12():
     assert all(np.isfinite(v) for v in eng.losses().values())
     with pytest.raises(ValueError, match="precision: bf16"):
         build_engine(dict(load_case("compact_small")[1], precision="bf16"), 1, *load_case("compact_small")[2:])
+
+
+@pytest.mark.parametrize("case,T", [("fc_small", 3), ("fc_example", 2)])
+def test_trial_batch_is_bitwise_the_trials_alone(case, T):
+    """VERDICT r2 item 3 / SURVEY 8f-3: T independent trials of the dense networks stepped by ONE launch sequence whose
+    kernels run with gridDim.z = T (``rankaae_amd.trial_batch.TrialBatch``).  Plane z runs the body the trial runs
+    alone on the trial's own buffers: after six steps (eager first step, captured graph, replays, a ragged batch
+    through a second program) every trial's weights, Adam moments, BatchNorm statistics and losses are BIT FOR BIT those
+    of the same trial stepped by itself."""
+    from rankaae_amd.trial_batch import TrialBatch
+    g, cfg, spec, aux = load_case(case)
+    bs = cfg["batch_size"]
+    n_train = ref_train.split_rows(len(spec))[0]
+    ragged = n_train - 3 * bs if 2 <= n_train - 3 * bs < bs else bs // 2
+
+    def make(t, stream=None):
+        torch.manual_seed(100 + t)
+        cls = pm.AE_CLS_DICT[cfg["ae_form"]]
+        enc = cls["encoder"](nstyle=cfg["nstyle"], dropout_rate=cfg["dropout_rate"], dim_in=cfg["dim_in"], n_layers=cfg["n_layers"])
+        dec = cls["decoder"](nstyle=cfg["nstyle"], dropout_rate=cfg["dropout_rate"], last_layer_activation=cfg["decoder_activation"],
+                             dim_out=cfg["dim_out"], n_layers=cfg["n_layers"])
+        dis = pm.DiscriminatorFC(nstyle=cfg["nstyle"], dropout_rate=cfg["dis_dropout_rate"], noise=cfg["dis_noise"],
+                                 layers=cfg["FC_discriminator_layers"])
+        eng = StepEngine(enc, dec, dis, cfg, DEV, rng_mode="philox", seed=500 + t, use_graph=True, stream=stream)
+        eng.set_data(spec[:n_train], aux[:n_train])
+        return eng
+
+    def state(e):
+        torch.cuda.synchronize()
+        return ([e.arena.P.clone()] + [b_.clone() for mod in (e.enc_mod, e.dec_mod) for b_ in mod.buffers()] +
+                [o.m.clone() for o in e.opts.values()] + [o.v.clone() for o in e.opts.values()], e.losses())
+
+    def perm(t, ep):
+        return torch.randperm(n_train, generator=torch.Generator().manual_seed(1000 * t + ep))
+    alone = []
+    for t in range(T):
+        e = make(t)
+        for ep in range(2):
+            e.set_epoch(perm(t, ep), 0.3)
+            for _ in range(3):
+                e.step(bs)
+            e.step(ragged)
+        alone.append(state(e))
+    shared = TrialBatch.shared_stream(DEV)
+    engs = [make(t, shared) for t in range(T)]
+    batch = TrialBatch(engs)
+    for ep in range(2):
+        for t, e in enumerate(engs):
+            e.set_epoch(perm(t, ep), 0.3)
+        for _ in range(3):
+            batch.step(bs)
+        batch.step(ragged)
+    assert batch.programs[(bs, True)][1] is not None and batch.launches_per_step(bs) > 50
+    for t, e in enumerate(engs):
+        got = state(e)
+        for a, b in zip(alone[t][0], got[0]):
+            assert torch.equal(a, b), f"trial {t} differs from the same trial alone"
+        assert alone[t][1] == got[1]
+    batch.release()
