@@ -504,7 +504,8 @@ __global__ __launch_bounds__(256) void mse_kernel_m(const MseArgs* t) {
 // functions.py:119-130: mean_i softplus(-o_i) over real + mean_i softplus(o_i) over fake.
 __device__ __forceinline__ double softplus_d(double x) { return x > 0.0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
 
-__global__ __launch_bounds__(1024) void bce_pair_kernel(const float* o, int n_real, int n_fake, float* loss, float* d) {
+struct BceArgs { const float* o; int n_real; int n_fake; float* loss; float* d; };
+__device__ __forceinline__ void bce_pair_body(const float* o, int n_real, int n_fake, float* loss, float* d) {
     __shared__ double shd[16];
     double acc = 0.0;
     for (int i = threadIdx.x; i < n_real + n_fake; i += 1024) {
@@ -517,8 +518,15 @@ __global__ __launch_bounds__(1024) void bce_pair_kernel(const float* o, int n_re
     if (threadIdx.x == 0) loss[0] = (float)t;
 }
 
-__global__ void disc_input_kernel(const float* z_real, const float* styles, const float* noise, float sigma,
-                                  int n_real, int n_fake, int C, float* out) {
+__global__ __launch_bounds__(1024) void bce_pair_kernel(BceArgs a) { bce_pair_body(a.o, a.n_real, a.n_fake, a.loss, a.d); }
+__global__ __launch_bounds__(1024) void bce_pair_kernel_m(const BceArgs* t) {
+    const BceArgs a = t[blockIdx.z];
+    bce_pair_body(a.o, a.n_real, a.n_fake, a.loss, a.d);
+}
+
+struct DiscInArgs { const float* z_real; const float* styles; const float* noise; float sigma; int n_real; int n_fake; int C; float* out; };
+__device__ __forceinline__ void disc_input_body(const float* z_real, const float* styles, const float* noise, float sigma,
+                                                int n_real, int n_fake, int C, float* out) {
     const long n = (long)(n_real + n_fake) * C;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const long split = (long)n_real * C;
@@ -526,6 +534,12 @@ __global__ void disc_input_kernel(const float* z_real, const float* styles, cons
         if (noise) v += sigma * noise[i];
         out[i] = v;
     }
+}
+
+__global__ void disc_input_kernel(DiscInArgs a) { disc_input_body(a.z_real, a.styles, a.noise, a.sigma, a.n_real, a.n_fake, a.C, a.out); }
+__global__ void disc_input_kernel_m(const DiscInArgs* t) {
+    const DiscInArgs a = t[blockIdx.z];
+    disc_input_body(a.z_real, a.styles, a.noise, a.sigma, a.n_real, a.n_fake, a.C, a.out);
 }
 
 __global__ void scale_by_dev_kernel(const float* src, const float* dev_scale, float sign, long n, float* dst) {
@@ -738,7 +752,8 @@ extern "C" int raae_mse_fwd_bwd(const float* a, const float* b, long n, double* 
 
 extern "C" int raae_bce_pair_fwd_bwd(const float* logits, int n_real, int n_fake, float* loss, float* dlogits, void* stream) {
     RAAE_CHECK_ARG(logits && loss && n_real > 0 && n_fake > 0);
-    hipLaunchKernelGGL(bce_pair_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, n_real, n_fake, loss, dlogits);
+    const BceArgs a = {logits, n_real, n_fake, loss, dlogits};
+    raae::launch(bce_pair_kernel, bce_pair_kernel_m, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
     RAAE_LAUNCH_RET();
 }
 
@@ -746,8 +761,8 @@ extern "C" int raae_disc_input(const float* z_real, const float* styles, const f
                                int n_real, int n_fake, int C, float* out, void* stream) {
     RAAE_CHECK_ARG(z_real && styles && out && n_real > 0 && n_fake > 0 && C > 0);
     const long n = (long)(n_real + n_fake) * C;
-    hipLaunchKernelGGL(disc_input_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream,
-                       z_real, styles, noise, sigma, n_real, n_fake, C, out);
+    const DiscInArgs a = {z_real, styles, noise, sigma, n_real, n_fake, C, out};
+    raae::launch(disc_input_kernel, disc_input_kernel_m, dim3(grid_for(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, a);
     RAAE_LAUNCH_RET();
 }
 

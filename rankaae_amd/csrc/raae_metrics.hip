@@ -17,8 +17,9 @@ constexpr int kTile = 2048;
 // grid (ceil(n / 256), k).  rank[c][i] = #{x_j < x_i} + (#{x_j == x_i} + 1) / 2; the element's slot in the sorted
 // column is #{x_j < x_i} + #{j < i : x_j == x_i}; sorted[c][slot] = x_i - pivot_c (scipy subtracts x[n / 2],
 // "the median or a nearby value", before the W arithmetic).
-__global__ __launch_bounds__(256) void style_rank_kernel(const float* __restrict__ z, int n, int k,
-                                                         double* __restrict__ rank, double* __restrict__ sorted) {
+struct StyleRankArgs { const float* z; int n; int k; double* rank; double* sorted; };
+__device__ __forceinline__ void style_rank_body(const float* __restrict__ z, int n, int k,
+                                                double* __restrict__ rank, double* __restrict__ sorted) {
     __shared__ float tile[kTile];
     const int c = blockIdx.y, tid = threadIdx.x;
     const int i = blockIdx.x * 256 + tid;
@@ -71,12 +72,19 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double* red) {
     for (int u = 0; u < NV; ++u) v[u] = red[u * 256];
 }
 
+__global__ __launch_bounds__(256) void style_rank_kernel(StyleRankArgs a) { style_rank_body(a.z, a.n, a.k, a.rank, a.sorted); }
+__global__ __launch_bounds__(256) void style_rank_kernel_m(const StyleRankArgs* t) {       // one trial per grid plane
+    const StyleRankArgs a = t[blockIdx.z];
+    style_rank_body(a.z, a.n, a.k, a.rank, a.sorted);
+}
+
 // grid (k + k (k - 1) / 2).  Workgroups < k: W of column blockIdx.x; the others: rho of pair (p, q), p < q, in
 // itertools.combinations order.  out = [W_0 .. W_{k-1}, rho_(0,1), rho_(0,2), ...].
-__global__ __launch_bounds__(256) void style_stat_kernel(const double* __restrict__ rank,
-                                                         const double* __restrict__ sorted,
-                                                         const double* __restrict__ a, int n, int k,
-                                                         double* __restrict__ out) {
+struct StyleStatArgs { const double* rank; const double* sorted; const double* a; int n; int k; double* out; };
+__device__ __forceinline__ void style_stat_body(const double* __restrict__ rank,
+                                                const double* __restrict__ sorted,
+                                                const double* __restrict__ a, int n, int k,
+                                                double* __restrict__ out) {
     __shared__ double red[3 * 256];
     const int tid = threadIdx.x, w = blockIdx.x;
     if (w < k) {
@@ -129,6 +137,12 @@ __global__ __launch_bounds__(256) void style_stat_kernel(const double* __restric
 
 // out[g][l] = mean_s x[g][s][l]: the n_sampling average of the report's decoder sweeps (sc/report/analysis.py:78-86).
 // One thread per output column element; the sum runs in sample order in double.
+__global__ __launch_bounds__(256) void style_stat_kernel(StyleStatArgs a) { style_stat_body(a.rank, a.sorted, a.a, a.n, a.k, a.out); }
+__global__ __launch_bounds__(256) void style_stat_kernel_m(const StyleStatArgs* t) {
+    const StyleStatArgs a = t[blockIdx.z];
+    style_stat_body(a.rank, a.sorted, a.a, a.n, a.k, a.out);
+}
+
 __global__ __launch_bounds__(256) void group_mean_kernel(const float* __restrict__ x, int groups, int per, int L,
                                                          float* __restrict__ out) {
     const long n = (long)groups * L;
@@ -156,9 +170,9 @@ extern "C" int raae_style_metrics(const float* z, int n, int k, const double* a_
     RAAE_CHECK_ARG(z && a_coef && work && out && n >= 3 && k >= 1 && k <= 64);
     double* rank = work;
     double* sorted = work + (size_t)k * n;
-    hipLaunchKernelGGL(style_rank_kernel, dim3(raae::cdiv(n, 256), k), dim3(256), 0, (hipStream_t)stream, z, n, k,
-                       rank, sorted);
-    hipLaunchKernelGGL(style_stat_kernel, dim3(k + k * (k - 1) / 2), dim3(256), 0, (hipStream_t)stream, rank, sorted,
-                       a_coef, n, k, out);
+    const StyleRankArgs ra = {z, n, k, rank, sorted};
+    raae::launch(style_rank_kernel, style_rank_kernel_m, dim3(raae::cdiv(n, 256), k), dim3(256), 0, (hipStream_t)stream, ra);
+    const StyleStatArgs sa = {rank, sorted, a_coef, n, k, out};
+    raae::launch(style_stat_kernel, style_stat_kernel_m, dim3(k + k * (k - 1) / 2), dim3(256), 0, (hipStream_t)stream, sa);
     RAAE_LAUNCH_RET();
 }

@@ -206,12 +206,17 @@ __device__ __forceinline__ void fill_quad(float* tape, const int* seg_desc, cons
     for (int j = 0; j < 4; ++j) if (e0 + j < send && e0 + j < total) tape[e0 + j] = o[j];
 }
 
-__global__ __launch_bounds__(256) void rng_fill_kernel(float* tape, const int* seg_desc, const float* seg_scale, int nseg,
-                                                       long total, unsigned long long seed,
-                                                       const unsigned long long* counter) {
-    const unsigned long long ctr = counter ? counter[0] : 0ull;
-    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q * 4 < total; q += (long)gridDim.x * 256)
-        fill_quad(tape, seg_desc, seg_scale, nseg, total, seed, ctr, q);
+struct RngFillArgs { float* tape; const int* seg_desc; const float* seg_scale; int nseg; long total; unsigned long long seed;
+                     const unsigned long long* counter; };
+__device__ __forceinline__ void rng_fill_body(const RngFillArgs& a) {
+    const unsigned long long ctr = a.counter ? a.counter[0] : 0ull;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q * 4 < a.total; q += (long)gridDim.x * 256)
+        fill_quad(a.tape, a.seg_desc, a.seg_scale, a.nseg, a.total, a.seed, ctr, q);
+}
+__global__ __launch_bounds__(256) void rng_fill_kernel(RngFillArgs a) { rng_fill_body(a); }
+__global__ __launch_bounds__(256) void rng_fill_kernel_m(const RngFillArgs* t) {       // one trial per grid plane
+    const RngFillArgs a = t[blockIdx.z];
+    rng_fill_body(a);
 }
 
 // ---- the head of a training step in ONE launch (was: tick, tape fill, batch gather -- 19 us at 256 rows) ----
@@ -342,8 +347,8 @@ extern "C" int raae_rng_fill(float* tape, const int* seg_desc, const float* seg_
     long g = (total / 4 + 255) / 256;
     if (g > 4096) g = 4096;
     if (g < 1) g = 1;
-    hipLaunchKernelGGL(rng_fill_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, tape, seg_desc, seg_scale, nseg,
-                       total, seed, counter);
+    const RngFillArgs a = {tape, seg_desc, seg_scale, nseg, total, seed, counter};
+    raae::launch(rng_fill_kernel, rng_fill_kernel_m, dim3((int)g), dim3(256), 0, (hipStream_t)stream, a);
     RAAE_LAUNCH_RET();
 }
 

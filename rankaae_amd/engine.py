@@ -1244,7 +1244,9 @@ class StepEngine:
 
     # -- validation (trainer.py:206-268): eval-mode forward of the whole validation set
     @_on_stream
-    def validate(self, val_spec, val_aux, rng_host=True):
+    def validate(self, val_spec, val_aux, rng_host=True, _phase=None):
+        """``_phase`` (TrialBatch): "emit" -- launch the validation program eagerly and return ``(z, None)`` without
+        reading anything back; "read" -- only read the results of a program that has run."""
         c, dev, ns = self.cfg, self.device, self.nstyle
         nv, bc = val_spec.shape[0], c["batch_size"]
         key = ("val", nv)
@@ -1273,6 +1275,9 @@ class StepEngine:
             self.plans[key] = V
         V = self.plans[key]
         self._val_plan = V
+        if _phase == "read":
+            v = V.out.cpu().tolist()
+            return V.z, {k: v[i] for k, i in LOSS_SLOTS.items() if k != "mi_accum"}
         self.tape = V.tape
         if self.rng_mode == "host":
             torch.empty((), dtype=torch.int64).random_()     # the val DataLoader iterator's _base_seed draw
@@ -1308,6 +1313,9 @@ class StepEngine:
             V.metrics.launch(z)      # Shapiro-Wilk W per style, Spearman rho per pair (trainer.py:286-292)
             return z
 
+        if _phase == "emit":
+            V.z = emit()
+            return V.z, None
         # like the training step: eager once, captured on the second call, replayed afterwards (the inputs must
         # then be the same device tensors: the trainer validates on one resident split)
         same = getattr(V, "inputs", None) == (val_spec.data_ptr(), val_aux.data_ptr())

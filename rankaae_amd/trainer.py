@@ -153,8 +153,11 @@ class Trainer:
             try:
                 req = next(gen)
                 while True:
-                    eng.step(req[1], smooth=req[2])
-                    req = next(gen)
+                    if req[0] == "step":
+                        eng.step(req[1], smooth=req[2])
+                        req = next(gen)
+                    else:                                   # ("validate", spec, aux) -> (styles, losses)
+                        req = gen.send(eng.validate(req[1], req[2]))
             except StopIteration as done:
                 return done.value
         finally:
@@ -223,7 +226,7 @@ class Trainer:
                 tl["smooth"] = 0.0
             if self.world > 1:
                 eng.average_over_ranks(bn_buffers)
-            z, vl = eng.validate(val_spec, val_aux)
+            z, vl = yield ("validate", val_spec, val_aux)
             if epoch % 10 == 0 and lead:
                 self.loss_logger.info(
                     f"{epoch:d},\t"
@@ -306,20 +309,29 @@ def train_trials_batched(trainers, callbacks=None):
     gens = [t._train_epochs(cb) for t, cb in zip(trainers, callbacks)]
     results = [None] * len(trainers)
     try:
-        live = True
-        while live:
-            reqs = []
+        reqs = []
+        for i, g in enumerate(gens):
+            try:
+                reqs.append(next(g))
+            except StopIteration as done:
+                results[i] = done.value
+                reqs.append(None)
+        while not all(r is None for r in reqs):
+            if any(r is None for r in reqs) or any(r[0] != reqs[0][0] or (r[0] == "step" and r != reqs[0]) for r in reqs):
+                raise RuntimeError(f"the trials of a batch left lockstep: {[r and r[:1] for r in reqs]}")
+            if reqs[0][0] == "step":
+                batch.step(reqs[0][1], smooth=reqs[0][2])
+                answers = [None] * len(gens)
+            else:
+                answers = batch.validate([r[1] for r in reqs], [r[2] for r in reqs])
+            nxt = []
             for i, g in enumerate(gens):
                 try:
-                    reqs.append(next(g))
+                    nxt.append(next(g) if answers[i] is None else g.send(answers[i]))
                 except StopIteration as done:
                     results[i] = done.value
-                    reqs.append(None)
-            if all(r is None for r in reqs):
-                break
-            if any(r is None for r in reqs) or any(r != reqs[0] for r in reqs):
-                raise RuntimeError(f"the trials of a batch left lockstep: {reqs}")
-            batch.step(reqs[0][1], smooth=reqs[0][2])
+                    nxt.append(None)
+            reqs = nxt
         return results
     finally:
         for g in gens:

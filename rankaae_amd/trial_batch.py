@@ -80,6 +80,41 @@ class TrialBatch:
             for e in self.engines:
                 e._count_bn_step(smooth)
 
+    def validate(self, specs, auxs):
+        """The per-epoch validation of every trial (``StepEngine.validate``: eval forwards, five losses, style metrics) as
+        one launch sequence; ``specs`` / ``auxs``: each trial's resident validation split.  Returns ``[(z, losses)]``."""
+        lib = _lib.load()
+        key = ("val", int(specs[0].shape[0]), tuple(s.data_ptr() for s in specs))
+        with torch.cuda.stream(self.stream):
+            if key not in self.programs:
+                handles = (C.c_void_p * self.T)()
+                for t, e in enumerate(self.engines):
+                    check(lib.raae_record_begin(), "raae_record_begin")
+                    try:
+                        e.validate(specs[t], auxs[t], _phase="emit")
+                    finally:
+                        h, n = C.c_void_p(), C.c_int(0)
+                        rc = lib.raae_record_end(C.byref(h), C.byref(n))
+                    check(rc, "raae_record_end (a launch of the validation has no batched form)")
+                    handles[t] = h
+                torch.cuda.synchronize(self.engines[0].device)
+                prog = C.c_void_p()
+                rc = lib.raae_multi_build(handles, self.T, C.byref(prog))
+                for h in handles:
+                    lib.raae_record_free(C.c_void_p(h))
+                check(rc, "raae_multi_build (validation)")
+                self.programs[key] = [prog, None]
+            else:
+                prog, graph = self.programs[key]
+                if graph is None:
+                    graph = ops.Graph()
+                    graph.begin()
+                    check(lib.raae_multi_launch(prog, C.c_void_p(self.stream.cuda_stream)), "raae_multi_launch")
+                    graph.end()
+                    self.programs[key][1] = graph
+                graph.launch()
+            return [e.validate(specs[t], auxs[t], _phase="read") for t, e in enumerate(self.engines)]
+
     def launches_per_step(self, b, smooth=True):
         prog = self.programs.get((int(b), bool(smooth)))
         return _lib.load().raae_multi_count(prog[0]) if prog else 0

@@ -909,6 +909,9 @@ def test_trial_batch_is_bitwise_the_trials_alone(case, T):
         torch.cuda.synchronize()
         return ([e.arena.P.clone()] + [b_.clone() for mod in (e.enc_mod, e.dec_mod) for b_ in mod.buffers()] +
                 [o.m.clone() for o in e.opts.values()] + [o.v.clone() for o in e.opts.values()], e.losses())
+    n_val = ref_train.split_rows(len(spec))[1]
+    vs = torch.tensor(spec[n_train:n_train + n_val], dtype=torch.float32, device=DEV)
+    va = torch.tensor(aux[n_train:n_train + n_val], dtype=torch.float32, device=DEV)
 
     def perm(t, ep):
         return torch.randperm(n_train, generator=torch.Generator().manual_seed(1000 * t + ep))
@@ -920,7 +923,11 @@ def test_trial_batch_is_bitwise_the_trials_alone(case, T):
             for _ in range(3):
                 e.step(bs)
             e.step(ragged)
-        alone.append(state(e))
+        vals = []
+        for _ in range(3):                     # eager, captured, replayed
+            z, vl = e.validate(vs, va)
+            vals.append((z.clone(), vl, [m.copy() for m in e.val_style_metrics()]))
+        alone.append(state(e) + (vals,))
     shared = TrialBatch.shared_stream(DEV)
     engs = [make(t, shared) for t in range(T)]
     batch = TrialBatch(engs)
@@ -936,4 +943,12 @@ def test_trial_batch_is_bitwise_the_trials_alone(case, T):
         for a, b in zip(alone[t][0], got[0]):
             assert torch.equal(a, b), f"trial {t} differs from the same trial alone"
         assert alone[t][1] == got[1]
+    # the per-epoch validation as one launch sequence: eager + logged, captured, replayed -- the alone engine's numbers
+    for rep in range(3):
+        res = batch.validate([vs] * T, [va] * T)
+        for t, e in enumerate(engs):
+            z0, vl0, met0 = alone[t][2][rep]
+            assert torch.equal(res[t][0], z0) and res[t][1] == vl0, (t, rep, res[t][1], vl0)
+            W, rho = e.val_style_metrics()
+            assert (W == met0[0]).all() and (rho == met0[1]).all()
     batch.release()
