@@ -328,8 +328,8 @@ def trials_line(args, cfg, dev, spec, aux, counts=(1, 4, 8), rounds=150):
                    "hipGraph per trial, one host thread)", "batch": b, "aggregate_steps_per_s": out,
            "speedup_vs_one_trial": {k: round(v / base, 2) for k, v in out.items()},
            "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)")}
-    if cfg["ae_form"] == "FC":
-        # the dense networks' kernels also exist in a batched form: ONE launch sequence, gridDim.z = T
+    if True:
+        # every kernel of the step also exists in a batched form: ONE launch sequence, gridDim.z = T
         # (rankaae_amd.trial_batch.TrialBatch); each trial bit for bit what it is alone
         from rankaae_amd.trial_batch import TrialBatch
         bout = {}
@@ -368,7 +368,7 @@ def trials_line(args, cfg, dev, spec, aux, counts=(1, 4, 8), rounds=150):
             gc.collect()
             torch.cuda.empty_cache()
         res["batched_launches"] = {"unit": "the same, the T trials stepped by ONE launch sequence with gridDim.z = T "
-                                           "(TrialBatch; dense networks)", "aggregate_steps_per_s": bout,
+                                           "(TrialBatch)", "aggregate_steps_per_s": bout,
                                    "speedup_vs_one_trial": {k: round(v / base, 2) for k, v in bout.items()}}
     return res
 

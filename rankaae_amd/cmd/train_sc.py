@@ -204,12 +204,14 @@ def run_trials(trials, work_dir, train_config, verbose, data_file, timeout, logg
     if mode not in ("auto", "batched", "threads", "processes"):
         raise ValueError(f"trial_mode must be 'auto', 'batched', 'threads' or 'processes', not {mode!r}")
     philox = train_config.get("rng_mode", "philox") == "philox"
-    can_batch = (train_config.get("ae_form", None) == "FC" and philox and train_config.get("precision", "fp32") == "fp32" and
-                 train_config.get("fused_step_begin", True) and train_config.get("fused_discriminator", True))
+    dense = train_config.get("ae_form", None) == "FC"
+    can_batch = (philox and train_config.get("precision", "fp32") == "fp32" and
+                 train_config.get("fused_step_begin", True) and train_config.get("fused_discriminator", True) and
+                 (dense or int(train_config.get("batch_size", 0)) < 1024))
     if mode == "batched" and not can_batch:
-        raise ValueError("trial_mode: batched needs ae_form: FC, rng_mode: philox, precision: fp32 (the kernels of the "
-                         "dense-network step have the batched form; the conv networks use trial_mode: threads)")
-    if mode == "auto":      # dense networks: one launch sequence for all trials of a group; conv networks: threads
+        raise ValueError("trial_mode: batched needs rng_mode: philox, precision: fp32 and, for the conv networks, "
+                         "batch_size < 1024 (the large-batch conv kernels have no batched form: use trial_mode: threads)")
+    if mode == "auto":      # one launch sequence for all trials of a group where the step's kernels have the batched form
         mode = "batched" if can_batch else "threads"
     batched = mode == "batched"
     if batched:

@@ -306,6 +306,8 @@ inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // logs of T trials agree launch by launch and uploads the T argument blocks of every launch as one device table;
 // raae_multi_launch() replays the program with gridDim.z = T (capturable into a hipGraph).
 void record_launch(const void* multi_fn, dim3 grid, dim3 block, size_t lds, const void* args, size_t nbytes);
+void record_unsupported();          // a launch without a batched form: a recording in progress becomes invalid
+#define RAAE_PLAIN_LAUNCH(...) do { raae::record_unsupported(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 template <typename A>
 inline void launch(void (*single)(A), void (*multi)(const A*), dim3 grid, dim3 block, size_t lds, hipStream_t st, const A& a) {
     record_launch(reinterpret_cast<const void*>(multi), grid, block, lds, &a, sizeof(A));

@@ -546,8 +546,8 @@ extern "C" int raae_conv_fwd(const raae_view_t* in, int B, const raae_conv_t* cv
         h.in = *in; h.B = B; h.L = cv->Lin; h.w = w; h.bias = bias; h.out = out; h.act = act; h.nq = B * (cv->Lin >> 2);
         const int grid = head_grid(h.nq, cv->Cin <= 4 ? kHeadU : kHeadU / 2);
         if (out_nparts) *out_nparts = 0;
-        if (cv->Cin == 4) hipLaunchKernelGGL(head_fwd_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, h);
-        else hipLaunchKernelGGL(head_fwd_kernel<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, h);
+        if (cv->Cin == 4) raae::launch(head_fwd_kernel<4>, head_fwd_kernel_m<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, h);
+        else raae::launch(head_fwd_kernel<8>, head_fwd_kernel_m<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, h);
         RAAE_LAUNCH_RET();
     }
     if (conv_fwd_strip(a, out_nparts, (hipStream_t)stream)) RAAE_LAUNCH_RET();
@@ -560,15 +560,15 @@ extern "C" int raae_conv_fwd(const raae_view_t* in, int B, const raae_conv_t* cv
         const int grid = t.ngroups < RAAE_MAX_PARTS ? t.ngroups : RAAE_MAX_PARTS;
         t.a.nsl = grid;
         if (out_nparts) *out_nparts = grid;
-        if (B >= RAAE_BIG_ROWS) hipLaunchKernelGGL(conv_fwd_tiled_kernel<true>, dim3(grid), dim3(256), sizeof(float) * t.S * per_in,
+        if (B >= RAAE_BIG_ROWS) RAAE_PLAIN_LAUNCH(conv_fwd_tiled_kernel<true>, dim3(grid), dim3(256), sizeof(float) * t.S * per_in,
                            (hipStream_t)stream, t);
-        else hipLaunchKernelGGL(conv_fwd_tiled_kernel<false>, dim3(grid), dim3(256), sizeof(float) * t.S * per_in,
+        else RAAE_PLAIN_LAUNCH(conv_fwd_tiled_kernel<false>, dim3(grid), dim3(256), sizeof(float) * t.S * per_in,
                            (hipStream_t)stream, t);
         RAAE_LAUNCH_RET();
     }
     a.nsl = slices_for((long)B * cv->Lout, cv->Cout);
     if (out_nparts) *out_nparts = a.nsl;
-    hipLaunchKernelGGL(conv_fwd_kernel, dim3(a.nsl * cv->Cout), dim3(256), 0, (hipStream_t)stream, a);
+    RAAE_PLAIN_LAUNCH(conv_fwd_kernel, dim3(a.nsl * cv->Cout), dim3(256), 0, (hipStream_t)stream, a);
     RAAE_LAUNCH_RET();
 }
 
@@ -589,8 +589,8 @@ extern "C" int raae_head_bwd(const raae_grad_t* go, int B, const raae_conv_t* cv
     const int grid = head_grid(h.nq, 2);
     if (din_nparts) *din_nparts = grid;
     if (nslab) *nslab = grid;
-    if (cv->Cin == 4) hipLaunchKernelGGL(head_bwd_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, h);
-    else hipLaunchKernelGGL(head_bwd_kernel<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, h);
+    if (cv->Cin == 4) raae::launch(head_bwd_kernel<4>, head_bwd_kernel_m<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, h);
+    else raae::launch(head_bwd_kernel<8>, head_bwd_kernel_m<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, h);
     RAAE_LAUNCH_RET();
 }
 
@@ -611,15 +611,15 @@ extern "C" int raae_conv_bwd_data(const raae_grad_t* go, int B, const raae_conv_
         const int grid = t.ngroups < RAAE_MAX_PARTS ? t.ngroups : RAAE_MAX_PARTS;
         t.a.nsl = grid;
         if (din_nparts) *din_nparts = grid;
-        if (B >= RAAE_BIG_ROWS) hipLaunchKernelGGL(conv_bwd_data_tiled_kernel<true>, dim3(grid), dim3(256), sizeof(float) * t.S * per_g,
+        if (B >= RAAE_BIG_ROWS) RAAE_PLAIN_LAUNCH(conv_bwd_data_tiled_kernel<true>, dim3(grid), dim3(256), sizeof(float) * t.S * per_g,
                            (hipStream_t)stream, t);
-        else hipLaunchKernelGGL(conv_bwd_data_tiled_kernel<false>, dim3(grid), dim3(256), sizeof(float) * t.S * per_g,
+        else RAAE_PLAIN_LAUNCH(conv_bwd_data_tiled_kernel<false>, dim3(grid), dim3(256), sizeof(float) * t.S * per_g,
                            (hipStream_t)stream, t);
         RAAE_LAUNCH_RET();
     }
     a.nsl = slices_for((long)B * cv->Lin, cv->Cin);
     if (din_nparts) *din_nparts = a.nsl;
-    hipLaunchKernelGGL(conv_bwd_data_kernel, dim3(a.nsl * cv->Cin), dim3(256), 0, (hipStream_t)stream, a);
+    RAAE_PLAIN_LAUNCH(conv_bwd_data_kernel, dim3(a.nsl * cv->Cin), dim3(256), 0, (hipStream_t)stream, a);
     RAAE_LAUNCH_RET();
 }
 
@@ -643,14 +643,14 @@ extern "C" int raae_conv_bwd_weight(const raae_grad_t* go, int B, const raae_con
         { const int scap = (B + 127) / 128; if (t.S > scap) { t.S = scap; t.ngroups = (B + t.S - 1) / t.S; } }
         const int grid = t.ngroups < 128 ? t.ngroups : 128;
         if (nslab) *nslab = grid;
-        if (B >= RAAE_BIG_ROWS) hipLaunchKernelGGL(conv_bwd_weight_tiled_kernel<true>, dim3(grid), dim3(256), sizeof(float) * t.S * per,
+        if (B >= RAAE_BIG_ROWS) RAAE_PLAIN_LAUNCH(conv_bwd_weight_tiled_kernel<true>, dim3(grid), dim3(256), sizeof(float) * t.S * per,
                            (hipStream_t)stream, t);
-        else hipLaunchKernelGGL(conv_bwd_weight_tiled_kernel<false>, dim3(grid), dim3(256), sizeof(float) * t.S * per,
+        else RAAE_PLAIN_LAUNCH(conv_bwd_weight_tiled_kernel<false>, dim3(grid), dim3(256), sizeof(float) * t.S * per,
                            (hipStream_t)stream, t);
         RAAE_LAUNCH_RET();
     }
     if (nslab) *nslab = 1;
-    hipLaunchKernelGGL(conv_bwd_weight_kernel, dim3(a.nw + 2 * cv->Cout), dim3(256), 0, (hipStream_t)stream, a);
+    RAAE_PLAIN_LAUNCH(conv_bwd_weight_kernel, dim3(a.nw + 2 * cv->Cout), dim3(256), 0, (hipStream_t)stream, a);
     RAAE_LAUNCH_RET();
 }
 
@@ -672,13 +672,13 @@ extern "C" int raae_lenlin_fwd(const raae_view_t* in, int B, int C, int Lin, con
         const int grid = t.ngroups < RAAE_MAX_PARTS ? t.ngroups : RAAE_MAX_PARTS;
         t.a.nsl = grid;
         if (out_nparts) *out_nparts = grid;
-        hipLaunchKernelGGL(lenlin_fwd_tiled_kernel<false>, dim3(grid), dim3(256), sizeof(float) * (t.S * per + wfl),
+        RAAE_PLAIN_LAUNCH(lenlin_fwd_tiled_kernel<false>, dim3(grid), dim3(256), sizeof(float) * (t.S * per + wfl),
                            (hipStream_t)stream, t);
         RAAE_LAUNCH_RET();
     }
     a.nsl = slices_for((long)B * E, C);
     if (out_nparts) *out_nparts = a.nsl;
-    hipLaunchKernelGGL(lenlin_fwd_kernel, dim3(a.nsl * C), dim3(256), 0, (hipStream_t)stream, a);
+    RAAE_PLAIN_LAUNCH(lenlin_fwd_kernel, dim3(a.nsl * C), dim3(256), 0, (hipStream_t)stream, a);
     RAAE_LAUNCH_RET();
 }
 
@@ -699,13 +699,13 @@ extern "C" int raae_lenlin_bwd_data(const raae_grad_t* go, int B, int C, int E, 
         const int grid = t.ngroups < RAAE_MAX_PARTS ? t.ngroups : RAAE_MAX_PARTS;
         t.a.nsl = grid;
         if (din_nparts) *din_nparts = grid;
-        hipLaunchKernelGGL(lenlin_bwd_data_tiled_kernel<false>, dim3(grid), dim3(256), sizeof(float) * (t.S * per + wfl),
+        RAAE_PLAIN_LAUNCH(lenlin_bwd_data_tiled_kernel<false>, dim3(grid), dim3(256), sizeof(float) * (t.S * per + wfl),
                            (hipStream_t)stream, t);
         RAAE_LAUNCH_RET();
     }
     a.nsl = slices_for((long)B * Lin, C);
     if (din_nparts) *din_nparts = a.nsl;
-    hipLaunchKernelGGL(lenlin_bwd_data_kernel, dim3(a.nsl * C), dim3(256), 0, (hipStream_t)stream, a);
+    RAAE_PLAIN_LAUNCH(lenlin_bwd_data_kernel, dim3(a.nsl * C), dim3(256), 0, (hipStream_t)stream, a);
     RAAE_LAUNCH_RET();
 }
 
@@ -724,12 +724,12 @@ extern "C" int raae_lenlin_bwd_weight(const raae_grad_t* go, int B, int C, int E
         t.ngroups = (B + t.S - 1) / t.S;
         const int grid = t.ngroups < 64 ? t.ngroups : 64;
         if (nslab) *nslab = grid;
-        hipLaunchKernelGGL(lenlin_bwd_weight_tiled_kernel<false>, dim3(grid), dim3(256), sizeof(float) * t.S * per,
+        RAAE_PLAIN_LAUNCH(lenlin_bwd_weight_tiled_kernel<false>, dim3(grid), dim3(256), sizeof(float) * t.S * per,
                            (hipStream_t)stream, t);
         RAAE_LAUNCH_RET();
     }
     if (nslab) *nslab = 1;
-    hipLaunchKernelGGL(lenlin_bwd_weight_kernel, dim3(E * Lin + E + C), dim3(256), 0, (hipStream_t)stream, a);
+    RAAE_PLAIN_LAUNCH(lenlin_bwd_weight_kernel, dim3(E * Lin + E + C), dim3(256), 0, (hipStream_t)stream, a);
     RAAE_LAUNCH_RET();
 }
 
@@ -740,7 +740,7 @@ extern "C" int raae_sum3_fwd(const raae_view_t* a_, const raae_view_t* b_, const
     a.a = *a_; a.b = *b_; a.c = *c_; a.B = B; a.C = C; a.L = L; a.y = y; a.out_partials = out_partials;
     a.nsl = slices_for((long)B * L, C);
     if (out_nparts) *out_nparts = a.nsl;
-    hipLaunchKernelGGL(sum3_kernel, dim3(a.nsl * C), dim3(256), 0, (hipStream_t)stream, a);
+    RAAE_PLAIN_LAUNCH(sum3_kernel, dim3(a.nsl * C), dim3(256), 0, (hipStream_t)stream, a);
     RAAE_LAUNCH_RET();
 }
 
@@ -755,7 +755,7 @@ extern "C" int raae_grad_materialize(const raae_grad_t* go, int B, int C, int L,
     if (n < 1) n = 1;
     t.nsl = (int)n; t.slab_stride = slab_stride;
     if (nslab) *nslab = t.nsl;
-    hipLaunchKernelGGL(grad_materialize_sliced_kernel, dim3(t.nsl * C), dim3(256), 0, (hipStream_t)stream, t);
+    RAAE_PLAIN_LAUNCH(grad_materialize_sliced_kernel, dim3(t.nsl * C), dim3(256), 0, (hipStream_t)stream, t);
     RAAE_LAUNCH_RET();
 }
 
@@ -778,17 +778,19 @@ static bool use_big(int B, int kind, int family) {
 }
 // ---- shape-specialised instances of the fused block kernels (raae_block_shapes.inc)
 // (`big`: the instance for batches of >= 1024 rows, which carries the 16-byte staging / elementwise paths)
+// (the launch-bound instances go through raae::launch: they have the batched form KERNEL_m, one trial per grid plane; the
+// large-batch instances do not -- a recording that meets one is refused, raae::record_unsupported)
 #define RAAE_LAUNCH_KIND_BIG(KERNEL, ...) if (big) switch (kind) { \
-        case 0: hipLaunchKernelGGL((KERNEL<0, true>), __VA_ARGS__); break; case 1: hipLaunchKernelGGL((KERNEL<1, true>), __VA_ARGS__); break; \
-        case 2: hipLaunchKernelGGL((KERNEL<2, true>), __VA_ARGS__); break; case 3: hipLaunchKernelGGL((KERNEL<3, true>), __VA_ARGS__); break; \
-        case 4: hipLaunchKernelGGL((KERNEL<4, true>), __VA_ARGS__); break; case 5: hipLaunchKernelGGL((KERNEL<5, true>), __VA_ARGS__); break; \
-        case 6: hipLaunchKernelGGL((KERNEL<6, true>), __VA_ARGS__); break; default: hipLaunchKernelGGL((KERNEL<-1, true>), __VA_ARGS__); } \
+        case 0: RAAE_PLAIN_LAUNCH((KERNEL<0, true>), __VA_ARGS__); break; case 1: RAAE_PLAIN_LAUNCH((KERNEL<1, true>), __VA_ARGS__); break; \
+        case 2: RAAE_PLAIN_LAUNCH((KERNEL<2, true>), __VA_ARGS__); break; case 3: RAAE_PLAIN_LAUNCH((KERNEL<3, true>), __VA_ARGS__); break; \
+        case 4: RAAE_PLAIN_LAUNCH((KERNEL<4, true>), __VA_ARGS__); break; case 5: RAAE_PLAIN_LAUNCH((KERNEL<5, true>), __VA_ARGS__); break; \
+        case 6: RAAE_PLAIN_LAUNCH((KERNEL<6, true>), __VA_ARGS__); break; default: RAAE_PLAIN_LAUNCH((KERNEL<-1, true>), __VA_ARGS__); } \
     else RAAE_LAUNCH_KIND(KERNEL, __VA_ARGS__)
 #define RAAE_LAUNCH_KIND(KERNEL, ...) switch (kind) { \
-        case 0: hipLaunchKernelGGL(KERNEL<0>, __VA_ARGS__); break; case 1: hipLaunchKernelGGL(KERNEL<1>, __VA_ARGS__); break; \
-        case 2: hipLaunchKernelGGL(KERNEL<2>, __VA_ARGS__); break; case 3: hipLaunchKernelGGL(KERNEL<3>, __VA_ARGS__); break; \
-        case 4: hipLaunchKernelGGL(KERNEL<4>, __VA_ARGS__); break; case 5: hipLaunchKernelGGL(KERNEL<5>, __VA_ARGS__); break; \
-        case 6: hipLaunchKernelGGL(KERNEL<6>, __VA_ARGS__); break; default: hipLaunchKernelGGL(KERNEL<-1>, __VA_ARGS__); }
+        case 0: raae::launch(KERNEL<0, false>, KERNEL##_m<0>, __VA_ARGS__); break; case 1: raae::launch(KERNEL<1, false>, KERNEL##_m<1>, __VA_ARGS__); break; \
+        case 2: raae::launch(KERNEL<2, false>, KERNEL##_m<2>, __VA_ARGS__); break; case 3: raae::launch(KERNEL<3, false>, KERNEL##_m<3>, __VA_ARGS__); break; \
+        case 4: raae::launch(KERNEL<4, false>, KERNEL##_m<4>, __VA_ARGS__); break; case 5: raae::launch(KERNEL<5, false>, KERNEL##_m<5>, __VA_ARGS__); break; \
+        case 6: raae::launch(KERNEL<6, false>, KERNEL##_m<6>, __VA_ARGS__); break; default: raae::launch(KERNEL<-1, false>, KERNEL##_m<-1>, __VA_ARGS__); }
 static_assert(kNumBlkShapes == 7, "RAAE_LAUNCH_KIND enumerates the shape table");
 static bool same_conv(const raae_conv_t& x, const raae_conv_t& y) { return !memcmp(&x, &y, sizeof(raae_conv_t)); }
 // phase A kernels see (Cin, Cout, Lin, L1, Lout, E, cv1, cvs); phase B kernels (Cin, Cout, L1, Lout, cv2, cve)
@@ -912,11 +914,40 @@ __global__ __launch_bounds__(256) void block_fwd_b2_kernel(FwdB2Args k) {
     }
 }
 
+template <int K1, int K2>
+__global__ __launch_bounds__(256) void block_fwd_a2_kernel_m(const FwdA2Args* table) {      // one trial per grid plane
+    extern __shared__ __attribute__((aligned(16))) float dyn[];
+    __shared__ BlockFwdAArgs sa;
+    const FwdA2Args* k = table + blockIdx.z;
+    const int n1 = k->n1;
+    if ((int)blockIdx.x < n1) {
+        const BlockFwdAArgs& a = raae::args_from_ptr(&sa, &k->x);
+        block_fwd_a_body<K1>(a, blockIdx.x, n1, dyn);
+    } else {
+        const BlockFwdAArgs& a = raae::args_from_ptr(&sa, &k->y);
+        block_fwd_a_body<K2>(a, blockIdx.x - n1, gridDim.x - n1, dyn);
+    }
+}
+template <int K1, int K2>
+__global__ __launch_bounds__(256) void block_fwd_b2_kernel_m(const FwdB2Args* table) {
+    extern __shared__ __attribute__((aligned(16))) float dyn[];
+    __shared__ BlockFwdBArgs sa;
+    const FwdB2Args* k = table + blockIdx.z;
+    const int n1 = k->n1;
+    if ((int)blockIdx.x < n1) {
+        const BlockFwdBArgs& a = raae::args_from_ptr(&sa, &k->x);
+        block_fwd_b_body<K1>(a, blockIdx.x, n1, dyn);
+    } else {
+        const BlockFwdBArgs& a = raae::args_from_ptr(&sa, &k->y);
+        block_fwd_b_body<K2>(a, blockIdx.x - n1, gridDim.x - n1, dyn);
+    }
+}
+
 // instances: encoder block i beside decoder block i of the 256-point networks; anything else: two launches
 #define RAAE_FWD_PAIRS(KERNEL) \
-    if (k1 == 0 && k2 == 3) { hipLaunchKernelGGL((KERNEL<0, 3>), grid, dim3(256), lds, (hipStream_t)stream, k); RAAE_LAUNCH_RET(); } \
-    if (k1 == 1 && k2 == 4) { hipLaunchKernelGGL((KERNEL<1, 4>), grid, dim3(256), lds, (hipStream_t)stream, k); RAAE_LAUNCH_RET(); } \
-    if (k1 == 2 && k2 == 5) { hipLaunchKernelGGL((KERNEL<2, 5>), grid, dim3(256), lds, (hipStream_t)stream, k); RAAE_LAUNCH_RET(); }
+    if (k1 == 0 && k2 == 3) { raae::launch(KERNEL<0, 3>, KERNEL##_m<0, 3>, grid, dim3(256), lds, (hipStream_t)stream, k); RAAE_LAUNCH_RET(); } \
+    if (k1 == 1 && k2 == 4) { raae::launch(KERNEL<1, 4>, KERNEL##_m<1, 4>, grid, dim3(256), lds, (hipStream_t)stream, k); RAAE_LAUNCH_RET(); } \
+    if (k1 == 2 && k2 == 5) { raae::launch(KERNEL<2, 5>, KERNEL##_m<2, 5>, grid, dim3(256), lds, (hipStream_t)stream, k); RAAE_LAUNCH_RET(); }
 
 extern "C" int raae_block_fwd_a2(const raae_block_fwd_a_t* x, const raae_block_fwd_a_t* y, int* nparts_x, int* nparts_y,
                                  void* stream) {
@@ -1136,6 +1167,22 @@ __global__ __launch_bounds__(256) void block_bwd_b_wgrad_kernel(BwdBWgradArgs k)
     }
 }
 
+template <int KB, int KW>
+__global__ __launch_bounds__(256) void block_bwd_b_wgrad_kernel_m(const BwdBWgradArgs* table) {     // one trial per grid plane
+    extern __shared__ __attribute__((aligned(16))) float dyn[];
+    const BwdBWgradArgs* k = table + blockIdx.z;
+    const int nb = k->nb;
+    if ((int)blockIdx.x < nb) {
+        __shared__ BlockBwdBArgs sa;
+        const BlockBwdBArgs& a = raae::args_from_ptr(&sa, &k->b);
+        block_bwd_b_body<KB>(a, blockIdx.x, nb, dyn);
+    } else {
+        __shared__ WgradMultiArgs sm;
+        const WgradMultiArgs& m = raae::args_from_ptr(&sm, &k->w);
+        wgrad_multi_body<KW>(m, blockIdx.x - nb, dyn);
+    }
+}
+
 extern "C" int raae_block_bwd_b_wgrad(const raae_block_bwd_b_t* bin, const raae_block_wgrad_t* win, int* nparts,
                                       int* nslab, void* stream) {
     static thread_local BwdBWgradArgs k;
@@ -1152,11 +1199,11 @@ extern "C" int raae_block_bwd_b_wgrad(const raae_block_bwd_b_t* bin, const raae_
     // instances: phase B of block i-1 beside the weight gradients of block i, for the block sequences of the
     // 256-point networks (encoder 0,1,2; decoder 3,4,5,6); anything else runs the generic pair
 #define RAAE_PAIR(KB_, KW_) if (kindb == KB_ && kindw == KW_) { \
-        hipLaunchKernelGGL((block_bwd_b_wgrad_kernel<KB_, KW_>), grid, block, lds, (hipStream_t)stream, k); RAAE_LAUNCH_RET(); }
+        raae::launch(block_bwd_b_wgrad_kernel<KB_, KW_>, block_bwd_b_wgrad_kernel_m<KB_, KW_>, grid, block, lds, (hipStream_t)stream, k); RAAE_LAUNCH_RET(); }
     RAAE_PAIR(0, 1) RAAE_PAIR(1, 2) RAAE_PAIR(3, 4) RAAE_PAIR(4, 5) RAAE_PAIR(5, 6)
     RAAE_PAIR(2, 3) RAAE_PAIR(6, 0)      // across the networks: encoder's last block beside decoder block 0's tasks, and back
     RAAE_PAIR(6, -1)                     // the decoder's head conv (a lone generic task) beside its last block
 #undef RAAE_PAIR
-    hipLaunchKernelGGL((block_bwd_b_wgrad_kernel<-1, -1>), grid, block, lds, (hipStream_t)stream, k);
+    raae::launch(block_bwd_b_wgrad_kernel<-1, -1>, block_bwd_b_wgrad_kernel_m<-1, -1>, grid, block, lds, (hipStream_t)stream, k);
     RAAE_LAUNCH_RET();
 }

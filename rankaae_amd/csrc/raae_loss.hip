@@ -474,7 +474,8 @@ template <int NT>
 __global__ __launch_bounds__(256) void smooth_kernel(SmoothArgs a) { smooth_body<NT>(a.x, a.B, a.L, a.tp, a.partial, a.dx, a.fin); }
 template <int NT>
 __global__ __launch_bounds__(256) void smooth_kernel_m(const SmoothArgs* t) {
-    const SmoothArgs a = t[blockIdx.z];
+    __shared__ SmoothArgs slot;      // the taps are indexed at run time: a private copy would live in scratch memory
+    const SmoothArgs& a = raae::args_from_table(&slot, t);
     smooth_body<NT>(a.x, a.B, a.L, a.tp, a.partial, a.dx, a.fin);
 }
 
@@ -620,7 +621,7 @@ extern "C" int raae_stat_collapse2(const double* p1, int n1, int C1, double* o1,
                                    void* stream) {
     RAAE_CHECK_ARG(p1 && o1 && n1 > 0 && n1 <= RAAE_MAX_PARTS && C1 > 0 && C1 <= 256);
     RAAE_CHECK_ARG(!p2 || (o2 && n2 > 0 && n2 <= RAAE_MAX_PARTS && C2 > 0 && C2 <= 256));
-    hipLaunchKernelGGL(stat_collapse_kernel, dim3(p2 ? 2 : 1), dim3(256), 0, (hipStream_t)stream, p1, n1, C1, o1, p2, n2, C2, o2);
+    RAAE_PLAIN_LAUNCH(stat_collapse_kernel, dim3(p2 ? 2 : 1), dim3(256), 0, (hipStream_t)stream, p1, n1, C1, o1, p2, n2, C2, o2);
     RAAE_LAUNCH_RET();
 }
 
@@ -698,7 +699,7 @@ extern "C" int raae_rank_rows_pairs(const float* d_all, int ldd, const float* z_
     float *gpos, *gneg;
     const int rc = rank_pairs_launch(d_all, ldd, z_all, ldz, n_all, row0, nrows, n_aux, work, g, gpos, gneg, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(rank_totals_kernel, dim3(1), dim3(256), 0, st, (const RankWork*)work, g.nwg, n_aux, totals);
+    RAAE_PLAIN_LAUNCH(rank_totals_kernel, dim3(1), dim3(256), 0, st, (const RankWork*)work, g.nwg, n_aux, totals);
     RAAE_LAUNCH_RET();
 }
 
@@ -768,13 +769,13 @@ extern "C" int raae_disc_input(const float* z_real, const float* styles, const f
 
 extern "C" int raae_scale_by_dev(const float* src, const float* dev_scale, float sign, long n, float* dst, void* stream) {
     RAAE_CHECK_ARG(src && dev_scale && dst && n > 0);
-    hipLaunchKernelGGL(scale_by_dev_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, src, dev_scale, sign, n, dst);
+    RAAE_PLAIN_LAUNCH(scale_by_dev_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, src, dev_scale, sign, n, dst);
     RAAE_LAUNCH_RET();
 }
 
 extern "C" int raae_loss_finalize(const double* partial, int n, float scale, float* out, int slot, int acc_slot, void* stream) {
     RAAE_CHECK_ARG(partial && out && n > 0 && slot >= 0);
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n, scale, out, slot, acc_slot);
+    RAAE_PLAIN_LAUNCH(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n, scale, out, slot, acc_slot);
     RAAE_LAUNCH_RET();
 }
 
@@ -782,7 +783,7 @@ extern "C" int raae_gather_batch(const float* spec, const float* aux, const long
                                  const float* noise, float spec_noise, int B, int L, int n_aux, float* spec_out,
                                  float* aux_out, void* stream) {
     RAAE_CHECK_ARG(spec && aux && idx && spec_out && aux_out && B > 0 && L > 0 && n_aux > 0);
-    hipLaunchKernelGGL(gather_batch_kernel, dim3(grid_for((long)B * L, 256, 2048)), dim3(256), 0, (hipStream_t)stream,
+    RAAE_PLAIN_LAUNCH(gather_batch_kernel, dim3(grid_for((long)B * L, 256, 2048)), dim3(256), 0, (hipStream_t)stream,
                        spec, aux, idx, cursor, noise, spec_noise, B, L, n_aux, spec_out, aux_out);
     RAAE_LAUNCH_RET();
 }

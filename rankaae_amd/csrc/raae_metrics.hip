@@ -161,7 +161,7 @@ extern "C" int raae_group_mean(const float* x, int groups, int per, int L, float
     RAAE_CHECK_ARG(x && out && groups > 0 && per > 0 && L > 0);
     const long n = (long)groups * L;
     const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    hipLaunchKernelGGL(group_mean_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, groups, per, L, out);
+    RAAE_PLAIN_LAUNCH(group_mean_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, groups, per, L, out);
     RAAE_LAUNCH_RET();
 }
 

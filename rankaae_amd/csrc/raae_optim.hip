@@ -337,7 +337,7 @@ extern "C" int raae_adam_step(float* p, float* m, float* v, const float* g_slabs
 extern "C" int raae_step_tick(int* steps, int n, unsigned mask, unsigned long long* rng_counter, int* cursor,
                               int cursor_inc, void* stream) {
     RAAE_CHECK_ARG(steps && n >= 0 && n <= 32);
-    hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, steps, n, mask, rng_counter, cursor, cursor_inc);
+    RAAE_PLAIN_LAUNCH(tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, steps, n, mask, rng_counter, cursor, cursor_inc);
     RAAE_LAUNCH_RET();
 }
 
@@ -481,12 +481,12 @@ extern "C" int raae_slab_reduce(const float* g_slabs, long slab_stride, const un
     if (max_nslab > 16) {
         long g = (n + 31) / 32;
         if (g > 4096) g = 4096;
-        hipLaunchKernelGGL(slab_reduce_wide_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, g_slabs, slab_stride,
+        RAAE_PLAIN_LAUNCH(slab_reduce_wide_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, g_slabs, slab_stride,
                            seg_nslab, n, out);
     } else {
         long g = (n + 255) / 256;
         if (g > 4096) g = 4096;
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, g_slabs, slab_stride,
+        RAAE_PLAIN_LAUNCH(slab_reduce_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, g_slabs, slab_stride,
                            seg_nslab, n, out);
     }
     RAAE_LAUNCH_RET();
@@ -496,7 +496,7 @@ extern "C" int raae_slab_reduce(const float* g_slabs, long slab_stride, const un
 // ---------------------------------------------------------------- batched launches over trials (raae_common.h)
 #include <vector>
 namespace {
-struct LaunchRec { const void* fn; dim3 grid, block; unsigned lds, nbytes; unsigned char args[1536]; };
+struct LaunchRec { const void* fn; dim3 grid, block; unsigned lds, nbytes; unsigned char args[4096]; };
 struct Recording { std::vector<LaunchRec> recs; bool bad = false; };
 thread_local Recording* g_recording = nullptr;
 struct MultiProgram { std::vector<LaunchRec> recs; std::vector<size_t> off; unsigned char* table = nullptr; int T = 0; };
@@ -509,6 +509,9 @@ void raae::record_launch(const void* multi_fn, dim3 grid, dim3 block, size_t lds
     rec.fn = multi_fn; rec.grid = grid; rec.block = block; rec.lds = (unsigned)lds; rec.nbytes = (unsigned)nbytes;
     memcpy(rec.args, args, nbytes);
     r->recs.push_back(rec);
+}
+void raae::record_unsupported() {
+    if (g_recording) g_recording->bad = true;
 }
 extern "C" int raae_record_begin(void) {
     if (g_recording) return RAAE_EINVAL;

@@ -10,8 +10,9 @@ its weights are bit for bit those of the same trial stepped by itself (tests/tes
 
 The first step of every batch shape is run by each engine on its own (eagerly: that is where an engine records its
 gradient-slab tables) while the library logs its launches; from the second step on the batch replays one captured
-hipGraph.  All engines of a batch share one HIP stream.  Supported: ``ae_form: FC`` (every kernel of that path has the
-batched form), ``rng_mode: philox``, one GPU.
+hipGraph.  All engines of a batch share one HIP stream.  Supported: both networks at batches below 1024 rows (the
+launch-bound kernel instances have the batched form; a step that meets a large-batch instance or a per-layer kernel is
+refused with an error, never run partially), ``rng_mode: philox``, fp32, one GPU.
 """
 import ctypes as C
 
@@ -26,8 +27,8 @@ class TrialBatch:
         assert len(engines) >= 1
         e0 = engines[0]
         for e in engines:
-            if e.cfg["ae_form"] != "FC" or e.rng_mode != "philox" or e.world_size != 1 or e.bf16:
-                raise ValueError("a TrialBatch takes fp32 dense-network engines (ae_form: FC, rng_mode: philox) on one GPU")
+            if e.rng_mode != "philox" or e.world_size != 1 or e.bf16:
+                raise ValueError("a TrialBatch takes fp32 engines with the device RNG (rng_mode: philox) on one GPU")
             if e.stream is not e0.stream:
                 raise ValueError("the engines of a TrialBatch must share one HIP stream (StepEngine(..., stream=s))")
             if not e.cfg.get("fused_step_begin", True) or not e.cfg.get("fused_discriminator", True):
@@ -87,29 +88,43 @@ class TrialBatch:
         key = ("val", int(specs[0].shape[0]), tuple(s.data_ptr() for s in specs))
         with torch.cuda.stream(self.stream):
             if key not in self.programs:
-                handles = (C.c_void_p * self.T)()
+                handles, batched = [], True
                 for t, e in enumerate(self.engines):
-                    check(lib.raae_record_begin(), "raae_record_begin")
+                    if batched:
+                        check(lib.raae_record_begin(), "raae_record_begin")
                     try:
                         e.validate(specs[t], auxs[t], _phase="emit")
                     finally:
-                        h, n = C.c_void_p(), C.c_int(0)
-                        rc = lib.raae_record_end(C.byref(h), C.byref(n))
-                    check(rc, "raae_record_end (a launch of the validation has no batched form)")
-                    handles[t] = h
+                        if batched:
+                            h, n = C.c_void_p(), C.c_int(0)
+                            rc = lib.raae_record_end(C.byref(h), C.byref(n))
+                            if rc == 0:
+                                handles.append(h)
+                            else:
+                                # a validation split of >= 1024 rows meets the conv networks' large-batch kernel
+                                # instances, which have no batched form: the trials' validations then run one after the
+                                # other on the shared stream (still one captured graph, and still on the device)
+                                batched = False
                 torch.cuda.synchronize(self.engines[0].device)
-                prog = C.c_void_p()
-                rc = lib.raae_multi_build(handles, self.T, C.byref(prog))
+                prog = None
+                if batched:
+                    prog = C.c_void_p()
+                    rc = lib.raae_multi_build((C.c_void_p * self.T)(*[h.value for h in handles]), self.T, C.byref(prog))
                 for h in handles:
-                    lib.raae_record_free(C.c_void_p(h))
-                check(rc, "raae_multi_build (validation)")
+                    lib.raae_record_free(h)
+                if batched:
+                    check(rc, "raae_multi_build (validation)")
                 self.programs[key] = [prog, None]
             else:
                 prog, graph = self.programs[key]
                 if graph is None:
                     graph = ops.Graph()
                     graph.begin()
-                    check(lib.raae_multi_launch(prog, C.c_void_p(self.stream.cuda_stream)), "raae_multi_launch")
+                    if prog is not None:
+                        check(lib.raae_multi_launch(prog, C.c_void_p(self.stream.cuda_stream)), "raae_multi_launch")
+                    else:
+                        for t, e in enumerate(self.engines):
+                            e.validate(specs[t], auxs[t], _phase="emit")
                     graph.end()
                     self.programs[key][1] = graph
                 graph.launch()
@@ -124,7 +139,8 @@ class TrialBatch:
         torch.cuda.synchronize(self.engines[0].device)
         for prog, graph in self.programs.values():
             del graph
-            lib.raae_multi_free(prog)
+            if prog is not None:
+                lib.raae_multi_free(prog)
         self.programs = {}
 
     def __del__(self):

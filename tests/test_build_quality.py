@@ -13,7 +13,7 @@ CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 # of four waves per SIMD).  dense_fwd2_kernel<64, 4>: two by-value argument blocks overflow the scalar registers; the
 # compiler reserves a 20-byte frame for the SGPR spill bookkeeping but the ISA holds no scratch instruction (checked
 # with -save-temps).
-ALLOW = {r"dense_fwd2_kernelILi64ELi4E": 32, r"dense_bwd_kernelILi32ELi8E": 64, r"conv_fwd_strip_kernelI.*Lb1E": 32}
+ALLOW = {r"dense_fwd2_kernelILi64ELi4E": 32, r"dense_bwd_kernel(_m)?ILi32ELi8E": 64, r"conv_fwd_strip_kernelI.*Lb1E": 32}
 
 
 def _usage(src):

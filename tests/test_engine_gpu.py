@@ -880,7 +880,7 @@ def test_bf16_storage_mode_fc_512_aux12():
         build_engine(dict(load_case("compact_small")[1], precision="bf16"), 1, *load_case("compact_small")[2:])
 
 
-@pytest.mark.parametrize("case,T", [("fc_small", 3), ("fc_example", 2)])
+@pytest.mark.parametrize("case,T", [("fc_small", 3), ("fc_example", 2), ("compact_small", 3), ("compact_nstyle5", 2)])
 def test_trial_batch_is_bitwise_the_trials_alone(case, T):
     """VERDICT r2 item 3 / SURVEY 8f-3: T independent trials of the dense networks stepped by ONE launch sequence whose
     kernels run with gridDim.z = T (``rankaae_amd.trial_batch.TrialBatch``).  Plane z runs the body the trial runs
@@ -912,6 +912,10 @@ def test_trial_batch_is_bitwise_the_trials_alone(case, T):
     n_val = ref_train.split_rows(len(spec))[1]
     vs = torch.tensor(spec[n_train:n_train + n_val], dtype=torch.float32, device=DEV)
     va = torch.tensor(aux[n_train:n_train + n_val], dtype=torch.float32, device=DEV)
+    # a split of >= 1024 rows: the conv networks' large-batch kernel instances have no batched form, and the batch then
+    # runs the trials' validations one after the other inside its graph
+    reps = -(-1100 // n_val)
+    vs_big, va_big = vs.repeat(reps, 1)[:1100].contiguous(), va.repeat(reps, 1)[:1100].contiguous()
 
     def perm(t, ep):
         return torch.randperm(n_train, generator=torch.Generator().manual_seed(1000 * t + ep))
@@ -924,9 +928,10 @@ def test_trial_batch_is_bitwise_the_trials_alone(case, T):
                 e.step(bs)
             e.step(ragged)
         vals = []
-        for _ in range(3):                     # eager, captured, replayed
-            z, vl = e.validate(vs, va)
-            vals.append((z.clone(), vl, [m.copy() for m in e.val_style_metrics()]))
+        for x, y in ((vs, va), (vs_big, va_big)):
+            for _ in range(3):                     # eager, captured, replayed
+                z, vl = e.validate(x, y)
+                vals.append((z.clone(), vl, [m.copy() for m in e.val_style_metrics()]))
         alone.append(state(e) + (vals,))
     shared = TrialBatch.shared_stream(DEV)
     engs = [make(t, shared) for t in range(T)]
@@ -944,8 +949,9 @@ def test_trial_batch_is_bitwise_the_trials_alone(case, T):
             assert torch.equal(a, b), f"trial {t} differs from the same trial alone"
         assert alone[t][1] == got[1]
     # the per-epoch validation as one launch sequence: eager + logged, captured, replayed -- the alone engine's numbers
-    for rep in range(3):
-        res = batch.validate([vs] * T, [va] * T)
+    for rep in range(6):
+        x, y = (vs, va) if rep < 3 else (vs_big, va_big)
+        res = batch.validate([x] * T, [y] * T)
         for t, e in enumerate(engs):
             z0, vl0, met0 = alone[t][2][rep]
             assert torch.equal(res[t][0], z0) and res[t][1] == vl0, (t, rep, res[t][1], vl0)
