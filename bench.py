@@ -333,12 +333,15 @@ def trials_line(args, cfg, dev, spec, aux, counts=(1, 4, 8), rounds=150):
         # (rankaae_amd.trial_batch.TrialBatch); each trial bit for bit what it is alone
         from rankaae_amd.trial_batch import TrialBatch
         bout = {}
+        bcfg = dict(cfg)
+        if cfg["ae_form"] != "FC":
+            bcfg.setdefault("tile_rows_mult", 4)     # as train_sc's batched mode runs the conv networks (raae_tile_hint)
         for T in tuple(counts) + ((16,) if 16 not in counts else ()):
             shared = TrialBatch.shared_stream(dev)
             engs = []
             for t in range(T):
-                enc, dec, dis = build_models(cfg, 1234 + t)
-                e = StepEngine(enc, dec, dis, cfg, dev, rng_mode="philox", seed=99 + t, use_graph=True, stream=shared)
+                enc, dec, dis = build_models(bcfg, 1234 + t)
+                e = StepEngine(enc, dec, dis, bcfg, dev, rng_mode="philox", seed=99 + t, use_graph=True, stream=shared)
                 e.set_data(spec[:n_train], aux[:n_train])
                 engs.append(e)
             batch = TrialBatch(engs)
@@ -368,7 +371,8 @@ def trials_line(args, cfg, dev, spec, aux, counts=(1, 4, 8), rounds=150):
             gc.collect()
             torch.cuda.empty_cache()
         res["batched_launches"] = {"unit": "the same, the T trials stepped by ONE launch sequence with gridDim.z = T "
-                                           "(TrialBatch)", "aggregate_steps_per_s": bout,
+                                           "(TrialBatch)", "tile_rows_mult": bcfg.get("tile_rows_mult", 1),
+                                   "aggregate_steps_per_s": bout,
                                    "speedup_vs_one_trial": {k: round(v / base, 2) for k, v in bout.items()}}
     return res
 

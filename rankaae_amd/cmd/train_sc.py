@@ -135,6 +135,11 @@ def run_trials_batched(jobs, per_batch, work_dir, train_config, verbose, data_fi
     of the group is one launch sequence with ``gridDim.z = trials`` (``rankaae_amd.trainer.train_trials_batched``; dense
     networks).  Seeds, files and log lines per trial as in the thread mode: ``[(k, metrics, time_used)]``."""
     from rankaae_amd.trainer import train_trials_batched
+    if train_config.get("ae_form", None) != "FC" and train_config.get("tile_rows_mult", None) is None:
+        # conv networks: every trial's launches sized as its share of a 4x larger batch (raae_tile_hint; +18 % at 8
+        # trials, +26 % at 16).  Keyed on the trial MODE, not on the group size: a trial's result is the same whatever
+        # runs beside it
+        train_config = Parameters({**train_config.to_dict(), "tile_rows_mult": 4})
     ngpus = torch.cuda.device_count()
     local_id = int(os.environ.get("LOCAL_RANK", os.environ.get("SLURM_LOCALID", 0)))
     igpu = local_id % ngpus if ngpus > 0 else -1

@@ -499,6 +499,7 @@ bool conv_ok(const raae_conv_t* cv) {
 int conv_nw(const raae_conv_t* cv) {
     return cv->transposed ? cv->Cin * (cv->Cout / cv->groups) * cv->K : cv->Cout * (cv->Cin / cv->groups) * cv->K;
 }
+thread_local int g_tile_mult = 1;
 // samples per tile: enough outputs to occupy 256 threads, bounded by an LDS budget
 int pick_S(long floats_per_sample, long outputs_per_sample, int B, long lds_budget_floats, int min_out) {
     long S = (min_out + outputs_per_sample - 1) / outputs_per_sample;
@@ -506,7 +507,8 @@ int pick_S(long floats_per_sample, long outputs_per_sample, int B, long lds_budg
     const long cap = lds_budget_floats / (floats_per_sample > 0 ? floats_per_sample : 1);
     // large batches: about two groups per workgroup of a 512-workgroup grid, up to 4x the samples per group
     // (fewer barriers, more loads in flight per staging pass; measured at B = 4096: 180 -> 201 steps/s, 8x: 192)
-    long want = (B + 1023) / 1024;
+    const long Bh = (long)B * g_tile_mult;      // raae_tile_hint: size the groups for a caller that batches trials
+    long want = (Bh + 1023) / 1024;
     // small samples (a few KB per sample): ONE group per workgroup -- such kernels are a chain
     // of barrier-separated stages of a few microseconds each, and a second group repeats the chain
     // (measured at B = 4096: 217 -> 223 steps/s with the threshold anywhere between 1400 and 4400 floats per sample)
@@ -516,7 +518,7 @@ int pick_S(long floats_per_sample, long outputs_per_sample, int B, long lds_budg
     // half as many prologues; measured 1024 / 2048 / 4096 / 8192 rows: 521 -> 547, 390 -> 405, 272.5 -> 279.6,
     // 170.5 -> 168.9 steps/s against 512 workgroups
     static const long small_div = getenv("RAAE_PICK_DIV") ? atol(getenv("RAAE_PICK_DIV")) : 256;
-    if (floats_per_sample <= small_floats) want = (B + small_div - 1) / small_div;
+    if (floats_per_sample <= small_floats) want = (Bh + small_div - 1) / small_div;
     if (want > small_mult * S && floats_per_sample <= small_floats) want = small_mult * S;
     else
     if (want > 4 * S) want = 4 * S;
@@ -530,6 +532,12 @@ int lg2(int v) { if (v <= 0 || (v & (v - 1))) return -1; int s = 0; while ((1 <<
 const long kTileBudget = 10 * 1024;    // floats (40 KB) of dynamic LDS for staged tiles
 
 }  // namespace
+
+extern "C" int raae_tile_hint(int rows_multiplier) {
+    RAAE_CHECK_ARG(rows_multiplier >= 1 && rows_multiplier <= 64);
+    g_tile_mult = rows_multiplier;
+    return 0;
+}
 
 extern "C" int raae_conv_fwd(const raae_view_t* in, int B, const raae_conv_t* cv, const float* w, const float* bias,
                              float* out, int stats_kind, const float* out_slope, double* out_partials, int* out_nparts,

@@ -447,6 +447,7 @@ def _on_stream(fn):
 
     @functools.wraps(fn)
     def wrapper(self, *a, **kw):
+        ops.tile_hint(self.tile_mult)        # thread-local in the library: whatever engine ran last on this thread set its own
         with torch.cuda.stream(self.stream):
             return fn(self, *a, **kw)
     return wrapper
@@ -460,6 +461,7 @@ def _on_stream_io(fn):
 
     @functools.wraps(fn)
     def wrapper(self, *a, **kw):
+        ops.tile_hint(self.tile_mult)
         caller = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(caller)
         with torch.cuda.stream(self.stream):
@@ -485,6 +487,10 @@ class StepEngine:
             raise RuntimeError("rankaae_amd.engine needs an MI355X (no CPU/PyTorch fallback for the training path)")
         _lib.load()
         self.cfg, self.device = dict(cfg), device
+        # `tile_rows_mult`: the conv-network launches size their sample groups as for a batch this many times larger
+        # (raae_tile_hint) -- for engines whose steps are launched T at a time by a TrialBatch (train_sc sets 4 there)
+        self.tile_mult = int(self.cfg.get("tile_rows_mult", 1))
+        ops.tile_hint(self.tile_mult)
         self.world_size, self.rank, self.pg = int(world_size), int(rank), process_group
         self.graph_ar = None
         # (`stream`: engines of a TrialBatch share one stream -- their batched step is one launch sequence on it)

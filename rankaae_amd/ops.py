@@ -174,6 +174,11 @@ def dense_bwd(g, g_kind, g_partials, g_nparts, zout, out_slope, out_bn, B, N, x,
     return _probed("dense_bwd_kernel", nbytes, launch)
 
 
+def tile_hint(mult):
+    """Thread-local launch-geometry hint of the conv-network entry points (``raae_tile_hint``)."""
+    check(_lib.load().raae_tile_hint(int(mult)), "raae_tile_hint")
+
+
 def stat_collapse2(p1, n1, C1, o1, p2=None, n2=0, C2=0, o2=None):
     def launch():
         check(_lib.load().raae_stat_collapse2(_ptr(p1, torch.float64), n1, C1, _ptr(o1, torch.float64),

@@ -29,6 +29,8 @@ class TrialBatch:
         for e in engines:
             if e.rng_mode != "philox" or e.world_size != 1 or e.bf16:
                 raise ValueError("a TrialBatch takes fp32 engines with the device RNG (rng_mode: philox) on one GPU")
+            if e.tile_mult != engines[0].tile_mult:
+                raise ValueError("the engines of a TrialBatch must share one tile_rows_mult")
             if e.stream is not e0.stream:
                 raise ValueError("the engines of a TrialBatch must share one HIP stream (StepEngine(..., stream=s))")
             if not e.cfg.get("fused_step_begin", True) or not e.cfg.get("fused_discriminator", True):
@@ -41,6 +43,7 @@ class TrialBatch:
         return torch.cuda.Stream(device=device)
 
     def step(self, b, smooth=True):
+        ops.tile_hint(self.engines[0].tile_mult)
         """One training step of every trial on its next ``b`` rows."""
         lib = _lib.load()
         key = (int(b), bool(smooth))
@@ -85,6 +88,7 @@ class TrialBatch:
         """The per-epoch validation of every trial (``StepEngine.validate``: eval forwards, five losses, style metrics) as
         one launch sequence; ``specs`` / ``auxs``: each trial's resident validation split.  Returns ``[(z, losses)]``."""
         lib = _lib.load()
+        ops.tile_hint(self.engines[0].tile_mult)
         key = ("val", int(specs[0].shape[0]), tuple(s.data_ptr() for s in specs))
         with torch.cuda.stream(self.stream):
             if key not in self.programs:

@@ -880,7 +880,47 @@ def test_bf16_storage_mode_fc_512_aux12():
         build_engine(dict(load_case("compact_small")[1], precision="bf16"), 1, *load_case("compact_small")[2:])
 
 
-@pytest.mark.parametrize("case,T", [("fc_small", 3), ("fc_example", 2), ("compact_small", 3), ("compact_nstyle5", 2)])
+def test_tile_hint_changes_only_the_rounding():
+    """``tile_rows_mult`` (raae_tile_hint) regroups the samples of the conv-network launches: other partial sums, the
+    same arithmetic.  With the weights frozen (lr_base = 0, as in P4) four free-running steps of the same seed give the
+    five losses of every step within 1e-5 relative of the default geometry's and the BatchNorm running statistics
+    within 1e-5 (the partial statistics are float64: usually every bit agrees) from fewer workgroups; and the hint is per engine -- an engine without it, run afterwards on the same thread, is bitwise
+    what it was before."""
+    g, cfg, _, _ = load_case("compact_small")
+    cfg = dict(cfg, lr_base=0.0, batch_size=256)
+    spec, aux, _ = make_spectra(1600, g["n_points"], cfg["n_aux"], seed=9)
+    n_train = ref_train.split_rows(len(spec))[0]
+
+    def run(mult):
+        c = dict(cfg) if mult is None else dict(cfg, tile_rows_mult=mult)
+        e = build_engine(c, 77, spec, aux, use_graph=True, rng_mode="philox")
+        e.set_epoch(torch.randperm(n_train, generator=torch.Generator().manual_seed(3)), 0.5)
+        out = []
+        for _ in range(4):
+            e.step(256)
+            out.append(e.losses())
+        torch.cuda.synchronize()
+        stats = [b_.clone() for mod in (e.enc_mod, e.dec_mod) for b_ in mod.buffers()]
+        parts = [w.nY for w in e.plans[256].enc.blk] + [w.nY for w in e.plans[256].dec.blk]   # partial-statistic rows = workgroups
+        e.release()
+        return (out, parts), stats
+    base, sb = run(None)
+    hint, sh = run(4)
+    again, sa = run(None)
+    assert base == again and all(torch.equal(x, y) for x, y in zip(sb, sa))
+    assert sum(hint[1]) < sum(base[1]), ("the hint did not change the launch geometry", base[1], hint[1])
+    for l0, l1 in zip(base[0], hint[0]):
+        for k in KEYS:
+            # (the rank loss weighs pair COUNTS: a pair whose style difference is rounding noise moves it by 4/(b^2-b))
+            tol = 3 * 4.0 / (256 * 255) if k == "kendall" else 1e-5 * max(abs(l0[k]), 1e-3)
+            assert abs(l0[k] - l1[k]) <= tol, (k, l0[k], l1[k])
+    for x, y in zip(sb, sh):
+        if x.dtype.is_floating_point:
+            assert torch.allclose(x, y, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("case,T", [("fc_small", 3), ("fc_example", 2), ("compact_small", 3), ("compact_nstyle5", 2),
+                                    ("compact_small+tile4", 3)])
 def test_trial_batch_is_bitwise_the_trials_alone(case, T):
     """VERDICT r2 item 3 / SURVEY 8f-3: T independent trials of the dense networks stepped by ONE launch sequence whose
     kernels run with gridDim.z = T (``rankaae_amd.trial_batch.TrialBatch``).  Plane z runs the body the trial runs
@@ -888,7 +928,9 @@ def test_trial_batch_is_bitwise_the_trials_alone(case, T):
     through a second program) every trial's weights, Adam moments, BatchNorm statistics and losses are BIT FOR BIT those
     of the same trial stepped by itself."""
     from rankaae_amd.trial_batch import TrialBatch
-    g, cfg, spec, aux = load_case(case)
+    g, cfg, spec, aux = load_case(case.split("+")[0])
+    if case.endswith("+tile4"):          # train_sc's batched mode for the conv networks: launch geometry of a 4x larger batch
+        cfg = dict(cfg, tile_rows_mult=4)
     bs = cfg["batch_size"]
     n_train = ref_train.split_rows(len(spec))[0]
     ragged = n_train - 3 * bs if 2 <= n_train - 3 * bs < bs else bs // 2

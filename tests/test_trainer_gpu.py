@@ -261,12 +261,12 @@ def test_train_sc_command_line_and_trial_workers(workers, tmp_path):
 
 
 @pytest.mark.parametrize("case,mode", [("compact_small", "threads"), ("fc_small", "threads"), ("fc_small", "batched"),
-                                       ("fc_small", "auto")])
+                                       ("fc_small", "auto"), ("compact_small", "batched"), ("compact_small", "auto")])
 def test_train_sc_concurrent_trials_equal_the_trial_alone(case, mode, tmp_path):
     """VERDICT r2 item 3 (the reference's real workload: ``trials: 8`` in example/fix_config.yaml): the
     trials of a run share the GPU -- ``trial_mode: threads`` runs them in threads of one process, each with its own
     engine, HIP stream, captured graph and host generator (seed ``trial_seed + k``); ``trial_mode: batched`` (what
-    ``auto`` picks for the dense networks) trains them in lockstep, every step of the group ONE launch sequence with
+    ``auto`` picks) trains them in lockstep, every step of the group ONE launch sequence with
     ``gridDim.z = trials``.  What runs beside a trial must not change it: trial 2 of a three-trial concurrent run ends
     with BITWISE the weights (and metrics) of the same trial run alone, and the reference's directory layout is
     written for every trial."""
