@@ -497,8 +497,9 @@ int raae_multi_free(void* program);
  * workgroups, fewer partial-statistic rows for every consumer: raae_tile_hint(m) makes the calling thread's following
  * launches size their groups as if the batch were m times larger (1 <= m <= 64; 1 = default).  It changes the
  * summation order of batch reductions (never which instance runs), so the SAME hint must be used wherever bitwise
- * equality is expected.  Measured, conv networks, 256 rows: m = 4: 8 batched trials 2245 -> 2628 aggregate steps/s,
- * 16 trials 2478 -> 3129; one trial alone 775 -> 645. */
+ * equality is expected.  A block's weight-gradient tasks get 128 / m workgroups (= gradient slabs) each.  Measured, conv
+ * networks, 256 rows: m = 4: 8 batched trials 2245 -> 2995 aggregate steps/s, 16 trials 2478 -> 3667; one trial alone
+ * 782 -> 620. */
 int raae_tile_hint(int rows_multiplier);
 
 /* ---- stream / graph / event plumbing (HIP runtime; used by the engine and bench.py) ---- */

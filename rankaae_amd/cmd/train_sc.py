@@ -136,8 +136,8 @@ def run_trials_batched(jobs, per_batch, work_dir, train_config, verbose, data_fi
     networks).  Seeds, files and log lines per trial as in the thread mode: ``[(k, metrics, time_used)]``."""
     from rankaae_amd.trainer import train_trials_batched
     if train_config.get("ae_form", None) != "FC" and train_config.get("tile_rows_mult", None) is None:
-        # conv networks: every trial's launches sized as its share of a 4x larger batch (raae_tile_hint; +18 % at 8
-        # trials, +26 % at 16).  Keyed on the trial MODE, not on the group size: a trial's result is the same whatever
+        # conv networks: every trial's launches sized as its share of a 4x larger batch (raae_tile_hint; +33 % at 8
+        # trials, +48 % at 16).  Keyed on the trial MODE, not on the group size: a trial's result is the same whatever
         # runs beside it
         train_config = Parameters({**train_config.to_dict(), "tile_rows_mult": 4})
     ngpus = torch.cuda.device_count()

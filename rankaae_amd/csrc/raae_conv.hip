@@ -1083,6 +1083,8 @@ static int prep_block_wgrad(const raae_block_wgrad_t* in, int* nslab, WgradMulti
     m.ntask = 0;
     int total = 0;
     size_t dyn = 0;
+    // raae_tile_hint: a caller that launches T trials at once gets T times the workgroups anyway
+    const int kWgradTaskGrid = ::kWgradTaskGrid / g_tile_mult > 16 ? ::kWgradTaskGrid / g_tile_mult : 16;
     for (int i = 0; i < in->n_conv; ++i) {
         const raae_wgrad_conv_t& c = in->conv[i];
         const raae_conv_t* cv = &c.cv;
