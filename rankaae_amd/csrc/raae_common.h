@@ -15,6 +15,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 extern __device__ long long d_stamps[4][3][16];
 extern __device__ unsigned long long d_stage_sum[4][3][16], d_stage_cnt[4][3][16];
 extern __device__ long long d_stage_prev[4];
+extern __device__ unsigned long long d_kind_sum[8][4][16], d_kind_cnt[8][4][16];
 #endif
 namespace raae {
 

@@ -11,6 +11,7 @@
 __device__ long long d_stamps[4][3][16];
 __device__ unsigned long long d_stage_sum[4][3][16], d_stage_cnt[4][3][16];   // per kernel: ticks spent before stamp i, visits
 __device__ long long d_stage_prev[4];
+__device__ unsigned long long d_kind_sum[8][4][16], d_kind_cnt[8][4][16];     // the same per block shape (7 = generic), grids of > 128 workgroups
 #endif
 #include "raae_common.h"
 #include <string.h>
