@@ -12,6 +12,8 @@ prologue of whoever back-propagates through it (``raae_grad_t``).  Block dataflo
     E1 = fc1(dropout(R)); E2 = fc2(PReLU(E1)); E3 = conv_excit(bn_excit(PReLU(E2)))   (if Cin != Cout)
     Y  = PReLU2(T2) + PReLUs(Sh) + PReLUe(E3 | E2)
 """
+import os
+
 import torch
 from torch import nn
 
@@ -339,7 +341,11 @@ class CompactNet:
 
         def fork_wgrad():
             if forked:
-                eng.join_side_streams(keep=int(eng.cfg.get("wgrad_overlap_depth", 1)) - 1)
+                # at most TWO forked batches in flight: with main chain and auxiliary stream that is four concurrent
+                # branches, the most the graph executor of ROCm 7.0 / 7.2 replays safely -- a captured step with five
+                # (depth 3) crashed inside hipGraphLaunch in long sessions (rocgdb: hip::Graph::UpdateStreams reading a
+                # stale hip::Stream*, or AllocCaptureSetValidate under GraphKernelNode::CreateCommand), alone it passed
+                eng.join_side_streams(keep=min(int(eng.cfg.get("wgrad_overlap_depth", 1)), 2) - 1)
                 with eng.side_stream():
                     for pend in forked:
                         note_wgrad(pend, ops.block_wgrad(b, None, None, eng.arena.n, args=pend[0]))
@@ -407,7 +413,17 @@ class CompactNet:
                     # `wgrad_overlap_depth` such batches may be in flight at once (default 1: the previous one is
                     # joined before the next forks).
                     forked.append((wargs, convs, lins))
-                    if len(forked) >= int(eng.cfg.get("wgrad_fork_blocks", 2)) or i == 0:
+                    # The network whose backward ENDS the phase (nothing upstream wants its input gradient): what is
+                    # forked after its last block cannot hide behind anything -- the optimizer waits for it across a
+                    # fork and a join edge (~13 + ~10 us on the 4096-row timeline, plus the launches themselves: 65-75 us
+                    # of exposed tail per phase).  There the second-to-last block forks what is pending (it runs
+                    # beside the last block's two backward kernels) and the last block's tasks stay on the main chain.
+                    tail = dx_in is None and pending is None and bool(eng.cfg.get("wgrad_tail_inline", os.environ.get("RAAE_WGRAD_TAIL", "1") != "0"))
+                    if tail and i == 0:
+                        for pend in forked:
+                            note_wgrad(pend, ops.block_wgrad(b, None, None, eng.arena.n, args=pend[0]))
+                        forked.clear()
+                    elif len(forked) >= int(eng.cfg.get("wgrad_fork_blocks", 2)) or i == 0 or (tail and i == 1):
                         fork_wgrad()
                 else:
                     pending = (wargs, convs, lins)
