@@ -266,6 +266,7 @@ def configs2_line(args, cfg0, dev):
         t0 = time.perf_counter()
         for _ in range(per):
             one_step()
+        eng.finish()                  # (a deferred smoothness tail of the last step belongs to the window)
         torch.cuda.synchronize()
         rates.append(per / (time.perf_counter() - t0))
     dt = time.perf_counter() - t_all
@@ -317,6 +318,8 @@ def trials_line(args, cfg, dev, spec, aux, counts=(1, 4, 8), rounds=150):
         t0 = time.perf_counter()
         for _ in range(rounds):
             one_round()
+        for e in engs:
+            e.finish()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         out[str(T)] = round(T * rounds / dt, 1)
@@ -472,6 +475,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
+    eng.finish()        # `overlap_steps`: the last step's smoothness tail runs beside the NEXT step's head -- here there is none
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:

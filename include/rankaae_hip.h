@@ -502,6 +502,17 @@ int raae_multi_free(void* program);
  * 782 -> 620. */
 int raae_tile_hint(int rows_multiplier);
 
+/* ---- hand-over of a step's deferred tail (round 3; rankaae_amd.engine.StepEngine `overlap_steps`) ---------------------
+ * The smoothness phase of step k (trainer.py:189-200) updates only the decoder; after its encoder forward nothing in it
+ * reads encoder state, and nothing in phase A of step k+1 (trainer.py:113-127: encoder forward, discriminator, encoder
+ * backward) reads decoder state.  The engine therefore runs that tail beside the next step's phase A, as a second
+ * branch of the next step's graph.  raae_tail_prepare ends the step's head: dst[0..n) = src[0..n) (the styles, whose
+ * buffer the next forward overwrites), *step_counter += 1 (the tail optimizer's step count; the step head then leaves
+ * that bit out of its mask), and the two 32-bit dropout hash keys at rng_state + 2 copied to tail_state + 2 (the
+ * tail's dense kernels take their raae_maskgen_t.keys there).  Any pointer but src / dst may be NULL. */
+int raae_tail_prepare(const float* src, float* dst, long n, int* step_counter, const unsigned long long* rng_state,
+                      unsigned long long* tail_state, void* stream);
+
 /* ---- stream / graph / event plumbing (HIP runtime; used by the engine and bench.py) ---- */
 int raae_graph_begin(void* stream);
 int raae_graph_end(void* stream, void** graph_exec);
@@ -514,7 +525,7 @@ int raae_event_destroy(void* ev);
 int raae_stream_sync(void* stream);
 const char* raae_error_string(int code);
 int raae_device_info(int* cu_count, int* lds_bytes, char* name, int name_len);
-#define RAAE_ABI_VERSION 15
+#define RAAE_ABI_VERSION 16
 int raae_abi_version(void);
 /* First 16 hex digits of sha256 over include/rankaae_hip.h + csrc/raae_*.{h,inc,hip} at build time
  * (build.sh); the Python loader recomputes it and refuses a library built from other sources. */

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librankaae_hip.so")
 
 RAAE_MAX_PARTS = 512
-ABI_VERSION = 15
+ABI_VERSION = 16
 IN_NONE, IN_PRELU_BN_DROP, IN_PRELU_DROP = 0, 1, 2
 OUT_RAW, OUT_STATS_PRELU, OUT_STATS_RAW, OUT_SOFTPLUS, OUT_RELU = 0, 1, 2, 3, 4
 G_DIRECT, G_SOFTPLUS, G_PRELU_BN, G_PRELU, G_RELU = 0, 1, 2, 3, 4
@@ -221,6 +221,7 @@ SIGNATURES = {
     "raae_multi_count": (_I, [_P]),
     "raae_multi_free": (_I, [_P]),
     "raae_tile_hint": (_I, [_I]),
+    "raae_tail_prepare": (_I, [_P, _P, _L, _P, _P, _P, _P]),
     "raae_graph_begin": (_I, [_P]),
     "raae_graph_end": (_I, [_P, C.POINTER(C.c_void_p)]),
     "raae_graph_launch": (_I, [_P, _P]),

@@ -315,7 +315,30 @@ __global__ __launch_bounds__(256) void step_begin_kernel_m(const StepBeginArgs* 
     step_begin_body(a);
 }
 
+// Hand-over of a step's deferred tail (StepEngine, `overlap_steps`): the styles the tail's decoder reads are copied out of
+// the encoder's workspace (the next step's first forward overwrites it), the dropout hash keys of the step out of the
+// counter block (the next step's head rewrites them), and the tail optimizer's step count advances -- one small launch
+// at the end of the step's head.
+__global__ __launch_bounds__(256) void tail_prepare_kernel(const float* src, float* dst, long n, int* step_counter,
+                                                           const unsigned* keys_src, unsigned* keys_dst) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+    if (i == 0) {
+        if (step_counter) *step_counter += 1;
+        if (keys_src && keys_dst) { keys_dst[0] = keys_src[0]; keys_dst[1] = keys_src[1]; }
+    }
+}
+
 }  // namespace
+
+extern "C" int raae_tail_prepare(const float* src, float* dst, long n, int* step_counter, const unsigned long long* rng_state,
+                                 unsigned long long* tail_state, void* stream) {
+    RAAE_CHECK_ARG(src && dst && n > 0 && n <= (1l << 30));
+    RAAE_PLAIN_LAUNCH(tail_prepare_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, n,
+                      step_counter, rng_state ? (const unsigned*)(rng_state + 2) : nullptr,
+                      tail_state ? (unsigned*)(tail_state + 2) : nullptr);
+    RAAE_LAUNCH_RET();
+}
 
 extern "C" int raae_adam_step(float* p, float* m, float* v, const float* g_slabs, long slab_stride,
                               const unsigned short* seg_nslab, long n, const double* hyper, const int* step,

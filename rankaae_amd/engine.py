@@ -239,7 +239,7 @@ class FCNet:
         """``dict(mask=, gen=, mask_scale=)`` of layer i's dropout multipliers: a tape view, or the in-kernel generator."""
         off, shape, keep, inline = masks[i]
         if inline:
-            return dict(mask=None, gen=(self.eng.rng_state, -off - 1, keep), mask_scale=1.0)
+            return dict(mask=None, gen=(self.eng.gen_state, -off - 1, keep), mask_scale=1.0)
         if self.bf16:
             return dict(mask=self.eng.tape.view16(off, *shape), gen=None, mask_scale=1.0 / keep)
         return dict(mask=self.eng.tape.view(off, *shape), gen=None, mask_scale=1.0)
@@ -449,6 +449,8 @@ def _on_stream(fn):
     def wrapper(self, *a, **kw):
         ops.tile_hint(self.tile_mult)        # thread-local in the library: whatever engine ran last on this thread set its own
         with torch.cuda.stream(self.stream):
+            if fn.__name__ != "step" and getattr(self, "_tail", None) is not None:
+                self._run_tail()
             return fn(self, *a, **kw)
     return wrapper
 
@@ -465,6 +467,8 @@ def _on_stream_io(fn):
         caller = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(caller)
         with torch.cuda.stream(self.stream):
+            if getattr(self, "_tail", None) is not None:
+                self._run_tail()
             out = fn(self, *a, **kw)
         caller.wait_stream(self.stream)
         return out
@@ -494,6 +498,7 @@ class StepEngine:
         self.world_size, self.rank, self.pg = int(world_size), int(rank), process_group
         self.graph_ar = None
         # (`stream`: engines of a TrialBatch share one stream -- their batched step is one launch sequence on it)
+        self._shared_stream = stream is not None
         self.stream = stream if stream is not None else torch.cuda.Stream(device=device)      # hipGraph capture is illegal on the null stream
         self.stream.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(self.stream):
@@ -561,6 +566,7 @@ class StepEngine:
         # rng_counter aliases [0] for raae_step_tick / raae_rng_fill
         self.rng_state = torch.tensor([0, self.seed, 0], dtype=torch.int64, device=device)    # counter, seed, hash keys
         self.rng_counter = self.rng_state[0:1]
+        self.gen_state = self.rng_state       # where the dense kernels find the step's dropout hash keys (byte 16)
         # build-only key `inline_masks` (rng_mode "philox" only; default on): dropout multipliers are regenerated by
         # the kernels that apply them instead of written to and read from the random tape
         self.inline_masks = self.rng_mode == "philox" and bool(cfg.get("inline_masks", True))
@@ -572,6 +578,25 @@ class StepEngine:
         # spectral noise -- is one launch (raae_step_begin) instead of three
         self.fused_begin = bool(cfg.get("fused_step_begin", True))
         self.begin_ticket = torch.zeros(1, dtype=torch.int32, device=device)
+        # build-only key `overlap_steps` (EXPERIMENT, default off; needs the device RNG, captured graphs, one GPU, a stream
+        # of its own, a batch on the serial chain): the smoothness phase (trainer.py:189-200) updates only the decoder,
+        # and once its encoder forward has run nothing in it reads encoder state; phase A of the NEXT step
+        # (trainer.py:113-127) reads no decoder state.  The rest of the phase -- decoder forward, loss, decoder backward,
+        # Adam -- is therefore deferred (`_tail`) and runs on a second stream beside the next step's phase A (three
+        # single-stream graphs per step: `step`).  Same kernels, same operands, same order wherever there is a dependency:
+        # bit for bit the plain step (tests/test_engine_gpu.py::test_overlapped_steps_are_bitwise_the_plain_steps).  What
+        # the two would share is doubled: the random tape alternates between two buffers by step parity, the styles
+        # and the dropout hash keys of the step are copied aside and the tail optimizer's step count advances at the
+        # hand-over (raae_tail_prepare).  Every other public method first runs a pending tail (`finish`).
+        # Off by default because it does not pay on this runtime: alone on two streams the two
+        # graphs take max(177, 202) us, gated by the one event the tail needs they take 177 + 202.
+        self.defer_tail = (bool(cfg.get("overlap_steps", False)) and self.rng_mode == "philox" and self.world_size == 1 and
+                           bool(use_graph) and not self._shared_stream and self.fused_begin)
+        self._tail = None                     # (plan, parity) of the step whose smoothness tail has not run yet
+        self._step_no = 0
+        self.tail_stream = torch.cuda.Stream(device=device) if self.defer_tail else None
+        self._tail_ev = [torch.cuda.Event(), torch.cuda.Event()] if self.defer_tail else None
+        self.tail_state = [torch.zeros(3, dtype=torch.int64, device=device) for _ in range(2)] if self.defer_tail else None
         self.alpha_dev = torch.zeros(1, device=device)
         self.loss_out = torch.zeros(8, device=device)
         self.taps = gaussian_taps(17, 3.0).tolist()
@@ -831,6 +856,8 @@ class StepEngine:
         P.m_enc.append(self.enc.mask_slots(tape, b))            # phase E :191
         P.m_dec.append(self.dec.mask_slots(tape, b))
         tape.finalize(dev)
+        tape.bufs = [tape.buf, torch.zeros_like(tape.buf)] if self.defer_tail else [tape.buf]
+        P.styles_tail = torch.empty(b, ns, device=dev)
         P.rank_work = torch.empty(ops.rank_loss_work_bytes(b, self.n_aux), dtype=torch.uint8, device=dev)
         if self.rank_pairs_global:
             P.aux_all = torch.empty(self.world_size * b, self.n_aux, device=dev)
@@ -948,14 +975,22 @@ class StepEngine:
     def _begin_phase(self, record):
         self._slab_notes = np.zeros(self.arena.n // 64, dtype=np.int16) if record else None
 
-    def emit_step(self, P, smooth, record):
+    def emit_step(self, P, smooth, record, parity=0, defer=False, tail_join=None):
         """``record``: first (eager) emission -- slab counts are recorded into the Adam segment
-        tables.  Under graph capture ``record`` is False (no host->device copies)."""
+        tables.  Under graph capture ``record`` is False (no host->device copies).  ``parity``: which of the plan's
+        tape buffers this step fills and reads.  ``defer`` (`overlap_steps`): the smoothness phase stops behind its
+        encoder forward and hands the rest over (``_emit_tail`` runs it later); ``tail_join`` (under capture): cut the
+        graph behind phase A -- the PREVIOUS step's tail runs beside the first part and is waited for before the
+        second."""
         c, b, ns = self.cfg, P.b, self.nstyle
         self.tape = P.tape
         tape = P.tape
+        tape.buf = tape.bufs[parity % len(tape.bufs)]
+        self.gen_state = self.rng_state
         self._branch = b >= self.overlap_min_batch
-        mask_bits = 0b01111 | (0b10000 if smooth else 0)
+        # (deferred tail: its optimizer's step count advances at the hand-over, not here -- the previous step's tail may
+        # still be reading it)
+        mask_bits = 0b01111 | (0b10000 if (smooth and not defer) else 0)
         stride = self.cursor_stride if self.cursor_stride is not None else b
         if P.stride is None:
             P.stride = stride
@@ -1003,6 +1038,13 @@ class StepEngine:
         enc.backward(E, P.spec, P.m_enc[0], dst)
         self.join_aux()
         self._adam(P, "adversarial", self._slab_notes)
+        if tail_join:                    # the previous step's tail (decoder only) runs beside everything above: the
+            g = self._capture["cur"]     # step is TWO graphs, and the main stream waits for the tail between them
+            g.end()
+            self._capture["items"].append(g)
+            g = ops.Graph()
+            g.begin()
+            self._capture["cur"] = g
         # ---- phase B: rank correlation (:153-161)
         self._begin_phase(record)
         will_backprop(enc)
@@ -1046,7 +1088,10 @@ class StepEngine:
         dec.backward(D, z_s, P.m_dec[2], P.dspec, None, pending=left)
         self._adam(P, "mutual_info", self._slab_notes)
         # ---- phase E: smoothness (:189-200); encoder gradients are discarded by the reference
-        if smooth:
+        if smooth and defer:
+            styles = enc.forward(E, P.spec, P.m_enc[5])        # (its gradients are discarded: no backward)
+            ops.tail_prepare(styles, P.styles_tail, b * ns, self.steps_dev[4:], self.rng_state, self.tail_state[parity & 1])
+        elif smooth:
             self._begin_phase(record)
             styles = enc.forward(E, P.spec, P.m_enc[5])        # (its gradients are discarded: no backward)
             will_backprop(dec)
@@ -1056,6 +1101,36 @@ class StepEngine:
             dec.backward(D, styles, P.m_dec[3], P.dout, None)
             self._adam(P, "smoothness", self._slab_notes)
         self._slab_notes = None
+
+    def _emit_tail(self, P, parity):
+        """The deferred rest of a step's smoothness phase (``emit_step(defer=True)``): decoder forward on the styles set
+        aside, loss, decoder backward, Adam -- with the tape buffer and the dropout hash keys of ITS step."""
+        b = P.b
+        tape = P.tape
+        saved = (self.tape, tape.buf, self.gen_state)
+        self.tape = tape
+        tape.buf = tape.bufs[parity % len(tape.bufs)]
+        self.gen_state = self.tail_state[parity & 1]
+        enc, dec, D = self.enc, self.dec, P.dec
+        enc.collapse, dec.collapse = False, self.collapse_stats
+        out = dec.forward(D, P.styles_tail, P.m_dec[3])
+        dec.collapse = False
+        ops.smooth_loss_fwd_bwd(out, b, self.L, self.taps, P.lpart, P.dout, fin=(1.0, self.loss_out, 4, -1, P.ticket))
+        dec.backward(D, P.styles_tail, P.m_dec[3], P.dout, None)
+        self._adam(P, "smoothness", None)
+        self.tape, tape.buf, self.gen_state = saved
+
+    def _run_tail(self):
+        """Run a pending tail now, eagerly, on the current stream (before anything that reads or replaces what it
+        touches: losses, validation, exports, another batch size, the end of a run)."""
+        t, self._tail = self._tail, None
+        if t is not None:
+            self._emit_tail(*t)
+
+    @_on_stream
+    def finish(self):
+        """Complete the last step (its deferred smoothness tail, if any); every public method but ``step`` does so
+        itself -- call it before timing the end of a run of steps."""
 
     def _pre_step(self, b, smooth):
         """Host side of a step before anything is launched: plan, bounds check, device cursor priming, host tape."""
@@ -1084,10 +1159,49 @@ class StepEngine:
         """Run one training step on the next ``b`` rows of the epoch permutation."""
         P = self._pre_step(b, smooth)
         key = bool(smooth)
+        parity = self._step_no & 1
+        self._step_no += 1
+        # (only where the decoder forward the reference discards rides with phase B's encoder forward: run inline in
+        # phase A it would share the decoder's workspace and running statistics with the tail beside it)
+        defer = (self.defer_tail and b < self.overlap_min_batch and self.phase_hook is None and
+                 self.post_phase_hook is None and bool(self.cfg.get("pair_unused_forwards", True)) and
+                 getattr(self.enc, "pairable", False) and getattr(self.dec, "pairable", False))
+        if self._tail is not None and (not defer or self._tail[0] is not P or key not in P.graphs):
+            self._run_tail()               # another batch size / an eager step follows: nothing to run beside
         if key not in P.graphs:
             # first call: eager emission (records slab counts, sets kernel attributes) ...
-            self.emit_step(P, smooth, record=True)
+            self.emit_step(P, smooth, record=True, parity=parity)
             P.graphs[key] = None
+            return
+        if self.use_graph and defer:
+            # `overlap_steps`: one graph per (smoothness phase or not, tape parity, a tail of the previous step to run
+            # beside this step's phase A or not); this step's own tail stays pending
+            # Three single-stream graphs (a captured graph with branches is re-submitted node by node on the host at every
+            # launch -- ~0.8 ms for these 150 nodes, the step itself; single-stream graphs replay from prepared packets):
+            # H1 = head up to the end of phase A, H2 = the rest of the head, T = a tail.  T of the previous step goes to
+            # the tail stream behind an event of this stream, H2 waits for its end.
+            tail = self._tail
+            if (key, parity) not in P.graphs:
+                # both parities at once (a capture takes tens of milliseconds: better now than an epoch into a run)
+                for p_ in (0, 1):
+                    if (key, p_) not in P.graphs:
+                        P.graphs[(key, p_)] = self._capture_overlapped(P, smooth, p_)
+                    if smooth and ("tail", p_) not in P.graphs:
+                        P.graphs[("tail", p_)] = self._capture_tail(P, p_)
+            h1, h2 = P.graphs[(key, parity)]
+            main = torch.cuda.current_stream()
+            if tail is not None:
+                self._tail_ev[0].record(main)
+                self.tail_stream.wait_event(self._tail_ev[0])
+                with torch.cuda.stream(self.tail_stream):
+                    P.graphs[("tail", tail[1])].launch()
+                    self._tail_ev[1].record(self.tail_stream)
+            h1.launch()
+            if tail is not None:
+                main.wait_event(self._tail_ev[1])
+            h2.launch()
+            self._tail = (P, parity) if smooth else None
+            self._count_bn_step(smooth)
             return
         if self.use_graph and P.graphs[key] is None:
             # ... second call: capture; the capture itself does not execute, so launch it right away
@@ -1095,7 +1209,7 @@ class StepEngine:
             g = ops.Graph()
             g.begin()
             self._capture = {"cur": g, "items": []}
-            self.emit_step(P, smooth, record=False)
+            self.emit_step(P, smooth, record=False, parity=parity)
             self._capture["cur"].end()
             P.graphs[key] = self._capture["items"] + [self._capture["cur"]]
             self._capture = None
@@ -1108,7 +1222,34 @@ class StepEngine:
                     item()
             self._count_bn_step(smooth)
         else:
-            self.emit_step(P, smooth, record=False)
+            self.emit_step(P, smooth, record=False, parity=parity)
+
+    def _capture_overlapped(self, P, smooth, parity):
+        """The two graphs of one `overlap_steps` step: the head up to the end of phase A, and the rest of the head; the
+        step's own tail is left out."""
+        bn_saved = dict(self.bn_counts)
+        g = ops.Graph()
+        g.begin()
+        self._capture = {"cur": g, "items": []}
+        self.emit_step(P, smooth, record=False, parity=parity, defer=True, tail_join=True)
+        self._capture["cur"].end()
+        items = self._capture["items"] + [self._capture["cur"]]
+        self._capture = None
+        self.bn_counts = bn_saved
+        assert len(items) == 2 and all(isinstance(i, ops.Graph) for i in items), "a host callback cut the graph of an overlapped step"
+        return tuple(items)
+
+    def _capture_tail(self, P, parity):
+        bn_saved = dict(self.bn_counts)
+        g = ops.Graph()
+        g.begin()
+        self._capture = {"cur": g, "items": []}
+        self._emit_tail(P, parity)
+        g.end()
+        assert not self._capture["items"]
+        self._capture = None
+        self.bn_counts = bn_saved
+        return g
 
     # -- roofline probe (bench.py): HIP-event timing of every kernel family the step launches
     @_on_stream

@@ -174,6 +174,11 @@ def dense_bwd(g, g_kind, g_partials, g_nparts, zout, out_slope, out_bn, B, N, x,
     return _probed("dense_bwd_kernel", nbytes, launch)
 
 
+def tail_prepare(src, dst, n, step_counter, rng_state, tail_state):
+    check(_lib.load().raae_tail_prepare(_ptr(src), _ptr(dst), n, _ptr(step_counter, torch.int32), _ptr(rng_state, None),
+                                        _ptr(tail_state, None), _stream()), "raae_tail_prepare")
+
+
 def tile_hint(mult):
     """Thread-local launch-geometry hint of the conv-network entry points (``raae_tile_hint``)."""
     check(_lib.load().raae_tile_hint(int(mult)), "raae_tile_hint")

@@ -881,6 +881,51 @@ def test_bf16_storage_mode_fc_512_aux12():
         build_engine(dict(load_case("compact_small")[1], precision="bf16"), 1, *load_case("compact_small")[2:])
 
 
+@pytest.mark.parametrize("case", ["fc_small", "compact_small", "compact_nstyle5", "fc_example"])
+def test_overlapped_steps_are_bitwise_the_plain_steps(case):
+    """`overlap_steps` (experiment, off by default): the decoder-only rest of a step's smoothness phase runs on a second
+    stream beside the NEXT step's phase A (encoder and discriminator only).  Same kernels, same operands, same order wherever one depends on another: after two epochs -- full batches,
+    a ragged one (another plan: the pending tail is run first), steps without the smoothness phase, a validation in
+    between and a read of the losses (both complete the pending tail) -- parameters, Adam moments, BatchNorm
+    statistics and every loss are BIT FOR BIT those of the engine that runs each step whole."""
+    g, cfg, spec, aux = load_case(case)
+    bs = cfg["batch_size"]
+    n_train, n_val = ref_train.split_rows(len(spec))[:2]
+    ragged = n_train - 3 * bs if 2 <= n_train - 3 * bs < bs else bs // 2
+    vs = torch.tensor(spec[n_train:n_train + n_val], dtype=torch.float32, device=DEV)
+    va = torch.tensor(aux[n_train:n_train + n_val], dtype=torch.float32, device=DEV)
+
+    def run(overlap):
+        e = build_engine(dict(cfg, overlap_steps=overlap), 77, spec, aux, use_graph=True, rng_mode="philox")
+        assert e.defer_tail == overlap
+        out = []
+        for ep in range(3):
+            e.set_epoch(torch.randperm(n_train, generator=torch.Generator().manual_seed(10 + ep)), 0.4)
+            for k in range(3):
+                e.step(bs, smooth=ep < 2)
+                if ep == 1 and k == 1:
+                    out.append(e.losses())          # completes the pending tail in the middle of an epoch
+            e.step(ragged, smooth=ep < 2)
+            z, vl = e.validate(vs, va)
+            out.append((e.losses(), vl, z.clone()))
+        torch.cuda.synchronize()
+        state = ([e.arena.P.clone()] + [b_.clone() for mod in (e.enc_mod, e.dec_mod) for b_ in mod.buffers()] +
+                 [o.m.clone() for o in e.opts.values()] + [o.v.clone() for o in e.opts.values()] + [e.steps_dev.clone()])
+        pending = e._tail
+        e.release()
+        return out, state, pending
+    plain, sp, _ = run(False)
+    over, so, pending = run(True)
+    assert pending is None
+    for a, b in zip(plain, over):
+        if isinstance(a, dict):
+            assert a == b
+        else:
+            assert a[0] == b[0] and a[1] == b[1] and torch.equal(a[2], b[2])
+    for a, b in zip(sp, so):
+        assert torch.equal(a, b)
+
+
 def test_tile_hint_changes_only_the_rounding():
     """``tile_rows_mult`` (raae_tile_hint) regroups the samples of the conv-network launches: other partial sums, the
     same arithmetic.  With the weights frozen (lr_base = 0, as in P4) four free-running steps of the same seed give the
