@@ -540,6 +540,46 @@ __device__ __forceinline__ void dense_bwd_body(const DenseBwdArgs& a, float* sme
             const int n = gcol0 + h * 256;
             if (h == 1 && !(wideN && n < N16)) break;
             if (n >= N16) continue;
+            if constexpr (TPW >= 16) {
+                // Wide output layers (N > 64: the decoder's last layer, 64 -> 256): a thread owns a whole 16-row column
+                // of the tile.  Row by row that was 16 dependent round trips per tile (25 us for the layer at 256 rows
+                // against 11.5 us for a 64 x 64 layer); here the 32 operands are requested before the first is used.
+                // Same values, same order of the column's bias / slope sums.
+                if (wideN) {
+                    float gq[16], zq[16];
+                    const bool colok = n < a.N, needz = a.g_kind != RAAE_G_DIRECT;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = row0 + r;
+                        const bool ok = colok && row < a.B;
+                        const size_t o = (size_t)(ok ? row : 0) * a.N + (colok ? n : 0);
+                        gq[r] = ok ? a.g[o] : 0.f;
+                        zq[r] = (ok && needz) ? (zb ? bf16_at(a.zout, o) : a.zout[o]) : 0.f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float dz = 0.f;
+                        if (colok && row0 + r < a.B) {
+                            const float gv = gq[r], zv = zq[r];
+                            if (a.g_kind == RAAE_G_DIRECT) dz = gv;
+                            else if (a.g_kind == RAAE_G_SOFTPLUS) dz = gv * (1.f - expf(-2.f * zv));
+                            else if (a.g_kind == RAAE_G_RELU) dz = zv > 0.f ? gv : 0.f;
+                            else {
+                                float da = gv;
+                                if (a.g_kind == RAAE_G_PRELU_BN) {
+                                    const float y = (prelu(zv, o_slope[n]) - o_mean[n]) * o_rstd[n];
+                                    da = o_rstd[n] * (gv - m1[n] - y * m2[n]);
+                                }
+                                if (zv > 0.f) dz = da;
+                                else { dz = da * o_slope[n]; ds_acc[h] += (double)da * (double)zv; }
+                            }
+                            db_acc[h] += (double)dz;
+                        }
+                        Gs[r * a.pitch_g + n] = dz;
+                    }
+                    continue;
+                }
+            }
             for (int r = grow0; r < 16; r += grstep) {
                 const int row = row0 + r;
                 float dz = 0.f;
