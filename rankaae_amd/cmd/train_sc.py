@@ -28,6 +28,7 @@ import time
 import numpy as np
 import torch
 
+from rankaae_amd import _lib
 from rankaae_amd.logger import create_logger
 from rankaae_amd.parameter import Parameters
 from rankaae_amd.trainer import Trainer
@@ -124,17 +125,18 @@ def _trial_worker(worker, jobs, work_dir, config_dict, verbose, data_file, timeo
     os.environ["LOCAL_RANK"] = str(worker)
     cfg = Parameters(config_dict)
     if batched:
-        return run_trials_batched(jobs, threads, work_dir, cfg, verbose, data_file, timeout, trial_seed)
+        return run_trials_batched(jobs, threads, work_dir, cfg, verbose, data_file, timeout, trial_seed, auto=batched == 2)
     if threads <= 1:
         return [(k,) + tuple(run_training(k, work_dir, cfg, verbose, data_file, timeout)) for k in jobs]
     return run_trials_threaded(jobs, threads, work_dir, cfg, verbose, data_file, timeout, trial_seed)
 
 
-def run_trials_batched(jobs, per_batch, work_dir, train_config, verbose, data_file, timeout, trial_seed):
+def run_trials_batched(jobs, per_batch, work_dir, train_config, verbose, data_file, timeout, trial_seed, auto=False):
     """The trials ``jobs`` of this process, ``per_batch`` at a time, each group trained in LOCKSTEP: every training step
     of the group is one launch sequence with ``gridDim.z = trials`` (``rankaae_amd.trainer.train_trials_batched``; dense
     networks).  Seeds, files and log lines per trial as in the thread mode: ``[(k, metrics, time_used)]``."""
     from rankaae_amd.trainer import train_trials_batched
+    plain_config = train_config
     if train_config.get("ae_form", None) != "FC" and train_config.get("tile_rows_mult", None) is None:
         # conv networks: every trial's launches sized as its share of a 4x larger batch (raae_tile_hint; +33 % at 8
         # trials, +48 % at 16).  Keyed on the trial MODE, not on the group size: a trial's result is the same whatever
@@ -168,13 +170,30 @@ def run_trials_batched(jobs, per_batch, work_dir, train_config, verbose, data_fi
             timer = threading.Timer(float(timeout) * 3600.0, lambda: [t.request_stop("Training Overtime!") for t in trainers])
             timer.daemon = True
             timer.start()
+        refused = None
         try:
             metrics = train_trials_batched(trainers)
+        except (_lib.HipCallError, ValueError) as exc:
+            # a step of this configuration meets a kernel without the batched form (a per-layer fallback, an unusual
+            # shape): `trial_mode: batched` says so; `auto` trains the group in threads instead, from the start
+            if not auto:
+                raise
+            refused = exc
         finally:
             if timer is not None:
                 timer.cancel()
             for t in trainers:
                 t.engine.release()
+        if refused is not None:
+            logging.getLogger("Main").warning(f"trial_mode auto: batched launches refused ({refused}); trials "
+                                              f"{[k + 1 for k in group]} run in threads")
+            for lg in loggers:
+                for h in list(lg.handlers):
+                    h.close()
+                    lg.removeHandler(h)
+            del trainers
+            out += run_trials_threaded(group, min(4, len(group)), work_dir, plain_config, verbose, data_file, timeout, trial_seed)
+            continue
         time_used = time.time() - start
         for k, m, logger in zip(group, metrics, loggers):
             logger.info(m)
@@ -216,9 +235,10 @@ def run_trials(trials, work_dir, train_config, verbose, data_file, timeout, logg
     if mode == "batched" and not can_batch:
         raise ValueError("trial_mode: batched needs rng_mode: philox, precision: fp32 and, for the conv networks, "
                          "batch_size < 1024 (the large-batch conv kernels have no batched form: use trial_mode: threads)")
-    if mode == "auto":      # one launch sequence for all trials of a group where the step's kernels have the batched form
+    auto = mode == "auto"
+    if auto:                # one launch sequence for all trials of a group where the step's kernels have the batched form
         mode = "batched" if can_batch else "threads"
-    batched = mode == "batched"
+    batched = (2 if auto else 1) if mode == "batched" else 0
     if batched:
         mode = "threads"          # same process / seed plumbing below; the worker trains its group in lockstep instead
     seeded = train_config.get("trial_seed", None) is not None
@@ -233,8 +253,12 @@ def run_trials(trials, work_dir, train_config, verbose, data_file, timeout, logg
         if seed is None:
             seed = int(torch.empty((), dtype=torch.int64).random_().item()) & 0x3fffffff
         if nproc == 1:
-            run = run_trials_batched if batched else run_trials_threaded
-            done = sorted(run(list(range(trials)), threads, work_dir, train_config, verbose, data_file, timeout, seed))
+            if batched:
+                done = sorted(run_trials_batched(list(range(trials)), threads, work_dir, train_config, verbose, data_file,
+                                                 timeout, seed, auto=batched == 2))
+            else:
+                done = sorted(run_trials_threaded(list(range(trials)), threads, work_dir, train_config, verbose, data_file,
+                                                  timeout, seed))
             return [(m, t) for _, m, t in done], threads
         import multiprocessing as mp
         with mp.get_context("spawn").Pool(nproc) as pool:

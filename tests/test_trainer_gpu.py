@@ -307,3 +307,36 @@ def test_train_sc_concurrent_trials_equal_the_trial_alone(case, mode, tmp_path):
     # ... and the trials of one run differ from each other (different seeds)
     c = models[("together", 1)]["Encoder"].state_dict()
     assert any(not torch.equal(c[n], a["Encoder"].state_dict()[n]) for n in c)
+
+
+def test_train_sc_auto_mode_falls_back_to_threads_when_batching_is_refused(tmp_path):
+    """``trial_mode: auto`` picks the batched launch sequence; a configuration whose step meets a kernel without the
+    batched form (here: ``fused_blocks: false``, the per-layer conv kernels) is refused by the recorder at the first
+    step -- ``auto`` then trains the group in threads, from the start, and says so; ``batched`` raises."""
+    import subprocess
+    import sys
+    import yaml
+    with open(os.path.join(os.path.dirname(__file__), "golden", "ref_compact_small.json")) as f:
+        g = json.load(f)
+    spec, aux, grid = make_spectra(g["n_rows"], g["n_points"], g["config"]["n_aux"], seed=g["data_seed"])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "RANKAAE_TRIAL_WORKERS", "RANKAAE_TRIALS_PER_GPU"):
+        env.pop(k, None)
+    for mode, ok in (("auto", True), ("batched", False)):
+        wd = tmp_path / mode
+        wd.mkdir()
+        cfg = dict(g["config"])
+        cfg.update(max_epoch=2, data_file="data.csv", verbose=False, timeout=1, trial_mode=mode, trials=2, trial_seed=5,
+                   fused_blocks=False)
+        write_csv(str(wd / "data.csv"), spec, aux, grid)
+        with open(wd / "cfg.yaml", "w") as f:
+            yaml.safe_dump(cfg, f)
+        r = subprocess.run([sys.executable, "-m", "rankaae_amd.cmd.train_sc", "-c", "cfg.yaml", "-w", str(wd)],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert (r.returncode == 0) == ok, r.stderr[-3000:]
+        if ok:
+            assert "batched launches refused" in (wd / "main_process_message.txt").read_text() + r.stderr
+            for k in (1, 2):
+                assert "Training finished" in (wd / "training" / f"job_{k}" / "messages.txt").read_text()
+                assert (wd / "training" / f"job_{k}" / "final.pt").exists()
