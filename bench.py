@@ -24,7 +24,9 @@ import time
 
 
 import numpy as np
-import torch
+
+os.environ.setdefault("HSA_KERNARG_POOL_SIZE", str(32 << 20))     # before the HIP runtime initialises: rankaae_amd/__init__.py says why
+import torch  # noqa: E402
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
