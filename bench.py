@@ -273,12 +273,14 @@ def configs2_line(args, cfg0, dev):
         rates.append(per / (time.perf_counter() - t0))
     dt = time.perf_counter() - t_all
     steps = windows * per
+    order = list(rates)
     rates.sort()
     med = 0.5 * (rates[windows // 2 - 1] + rates[windows // 2])
     out = {"workload": f"BASELINE configs[2]: {rows}x{cfg['dim_in']} synthetic spectra (train split {n_train}), batch {b}, "
                        f"ae_form={cfg['ae_form']}", "value": round(med, 2), "unit": "steps/s",
            "windows": {"n": windows, "steps_each": per, "min": round(rates[0], 2), "median": round(med, 2),
-                       "max": round(rates[-1], 2), "all_windows_together": round(steps / dt, 2)},
+                       "max": round(rates[-1], 2), "all_windows_together": round(steps / dt, 2),
+                       "in_order": [round(r, 1) for r in order]},
            "spectra_per_s": round(med * b), "ms_per_step": round(1e3 / med, 3), "steps": steps}
     if not args.no_roofline:
         out["roofline"] = eng.roofline_probe(b, HBM_PEAK_GBS, reps=2)
