@@ -540,7 +540,7 @@ __device__ __forceinline__ void dense_bwd_body(const DenseBwdArgs& a, float* sme
             const int n = gcol0 + h * 256;
             if (h == 1 && !(wideN && n < N16)) break;
             if (n >= N16) continue;
-            if constexpr (TPW >= 16) {
+            if constexpr (TPW == 16) {       // (not the 32-tile instance: 64 more live registers spill there)
                 // Wide output layers (N > 64: the decoder's last layer, 64 -> 256): a thread owns a whole 16-row column
                 // of the tile.  Row by row that was 16 dependent round trips per tile (25 us for the layer at 256 rows
                 // against 11.5 us for a 64 x 64 layer); here the 32 operands are requested before the first is used.
