@@ -752,7 +752,11 @@ class StepEngine:
         self._cursor_primed = False
         self._host_cursor = int(start)       # host mirror of the device row cursor (bounds check)
         self.alpha_dev.fill_(float(alpha))
-        self.loss_out[LOSS_SLOTS["mi_accum"]] = 0.0
+        # (a fill kernel: `tensor[i] = 0.0` copies a host scalar from pageable memory, which makes the host wait for every
+        # step queued on the stream -- it drained the pipeline once per epoch, and a host hiccup right behind it, in the
+        # pinned-buffer copy above say, then cost the GPU its full length: the 10-25 % dips of 40-step windows at 4096 rows)
+        k = LOSS_SLOTS["mi_accum"]
+        self.loss_out[k:k + 1].zero_()
 
     @_on_stream
     def seek(self, start, stride=None):
