@@ -390,7 +390,9 @@ def _stop_worker(rank, world, port, work_dir, case):
     box = [None] * world
     dist.all_gather_object(box, (raised, len(seen)))
     assert all(b_[0] == "Training Overtime!" for b_ in box), box
-    assert box[0][1] == box[1][1] and 1 <= box[0][1] < 100000, box      # same epoch on every rank, long before the end
+    # same epoch on every rank, long before the end (an epoch of this run takes 0.5-2.4 s with two ranks on one GPU: the
+    # one-second timer fires during the first, second or third)
+    assert box[0][1] == box[1][1] and 0 <= box[0][1] < 100000, box
     assert elapsed < 120
     assert tr.engine.graph_ar is None and not tr._gc_frozen              # train()'s finally ran
     dist.barrier()
