@@ -617,8 +617,9 @@ class StepEngine:
         # side streams + the auxiliary stream 574; at B=4096 the branches win, 195 against 168; dense networks at
         # B=1024: 748 branched, 669 serial).
         # (With the weight gradients riding in the backward launches -- raae_block_bwd_b_wgrad -- the serial chain of
-        # the conv networks also wins at 1024 rows: 428 against 417; branches from 2048: 305 against 288.)
-        self.overlap_min_batch = int(self.cfg.get("overlap_min_batch", 2048 if self.cfg["ae_form"] == "compact" else 1024))
+        # the conv networks also wins at 1024 rows: 428 against 417; branches from 2048: 305 against 288.  Round 3,
+        # serial / branched: 512 rows 685 / 580, 1024 rows 553 / 512, 1536 rows 439 / 448: the threshold moved to 1536.)
+        self.overlap_min_batch = int(self.cfg.get("overlap_min_batch", 1536 if self.cfg["ae_form"] == "compact" else 1024))
         self._branch = True
         # one more stream for whole FORWARD chains whose result the step does not wait for (the two forwards
         # the reference runs only for their BatchNorm / RNG side effects): they run beside the critical chain

@@ -80,7 +80,7 @@ INLINE_CASES = {
                           over=dict(ae_form="compact", batch_size=4096)),
     "fc_b4096": dict(n_rows=6000, n_points=256, data_seed=4, model_seed=42,
                      over=dict(ae_form="FC", batch_size=4096)),
-    # 1024 rows, conv networks: the large-batch kernel instances on the SERIAL chain (branches start at 2048 rows;
+    # 1024 rows, conv networks: the large-batch kernel instances on the SERIAL chain (branches start at 1536 rows;
     # the merged backward-B + weight-gradient launches here, the per-family instance masks of raae_conv.hip)
     "compact_b1024": dict(n_rows=1600, n_points=256, data_seed=6, model_seed=43,
                           over=dict(ae_form="compact", batch_size=1024)),
