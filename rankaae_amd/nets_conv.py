@@ -345,7 +345,7 @@ class CompactNet:
                 # branches, the most the graph executor of ROCm 7.0 / 7.2 replays safely -- a captured step with five
                 # (depth 3) crashed inside hipGraphLaunch in long sessions (rocgdb: hip::Graph::UpdateStreams reading a
                 # stale hip::Stream*, or AllocCaptureSetValidate under GraphKernelNode::CreateCommand), alone it passed
-                eng.join_side_streams(keep=min(int(eng.cfg.get("wgrad_overlap_depth", 1)), 2) - 1)
+                eng.join_side_streams(keep=min(int(eng.cfg.get("wgrad_overlap_depth", 2)), 2) - 1)
                 with eng.side_stream():
                     for pend in forked:
                         note_wgrad(pend, ops.block_wgrad(b, None, None, eng.arena.n, args=pend[0]))
@@ -410,8 +410,9 @@ class CompactNet:
                     # consecutive blocks (default 2): an edge between two hardware queues costs the main chain ~13 us
                     # (rocprofv3 timeline of the 4096-row step: every fork delayed the next backward kernel by that
                     # much), a weight-gradient launch that starts one block later costs nothing.
-                    # `wgrad_overlap_depth` such batches may be in flight at once (default 1: the previous one is
-                    # joined before the next forks).
+                    # `wgrad_overlap_depth` such batches may be in flight at once (default 2 since the end of round 3:
+                    # 283.0 against 279.4 steps/s at 4096 rows, where in the decoder-last phases the side branch,
+                    # not the main chain, ends the phase; 1: the previous batch is joined before the next forks).
                     forked.append((wargs, convs, lins))
                     # The network whose backward ENDS the phase (nothing upstream wants its input gradient): what is
                     # forked after its last block cannot hide behind anything -- the optimizer waits for it across a

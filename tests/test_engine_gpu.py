@@ -785,14 +785,13 @@ def test_validation_matches_oracle(case):
         assert np.allclose(W, [shapiro(x).statistic for x in z_h.cpu().numpy().T], rtol=0, atol=1e-12)
 
 
-@pytest.mark.parametrize("ae_form,depth", [("compact", 1), ("FC", 1), ("compact", 2)])
+@pytest.mark.parametrize("ae_form,depth", [("compact", 2), ("FC", 2), ("compact", 1)])
 def test_branched_graph_is_bitwise_eager_b4096(ae_form, depth):
     """BASELINE configs[2]'s batch: from ``overlap_min_batch`` rows up the captured step is a BRANCHED graph (weight
     gradients on side streams, discarded forwards on the auxiliary stream).  Replaying it must be bit for bit the
-    eager launches, and two captures must agree with each other.  ``depth`` = 2: two forked batches of weight-gradient
-    launches in flight at once (``wgrad_overlap_depth``; the default keeps one) -- deeper overlap is where round 1 once
-    saw a captured graph differ from eager launches.  With today's kernels it does not (and is no faster: the main
-    chain is the critical path), so the default stays 1 and this case guards the deeper overlap.  The engine caps the
+    eager launches, and two captures must agree with each other.  ``depth`` = 2 (the default since the end of round 3):
+    two forked batches of weight-gradient launches in flight at once (``wgrad_overlap_depth``) -- deeper overlap is
+    where round 1 once saw a captured graph differ from eager launches; with today's kernels it does not.  The engine caps the
     depth at 2: a step graph with FIVE concurrent branches (depth 3: main chain, auxiliary stream, three side
     streams) crashed inside ``hipGraphLaunch`` on ROCm 7.0 / 7.2 in long test sessions (nets_conv.py, fork_wgrad)."""
     g, cfg, spec, aux = load_case("compact_b4096" if ae_form == "compact" else "fc_b4096")
