@@ -619,7 +619,9 @@ class StepEngine:
         # (With the weight gradients riding in the backward launches -- raae_block_bwd_b_wgrad -- the serial chain of
         # the conv networks also wins at 1024 rows: 428 against 417; branches from 2048: 305 against 288.  Round 3,
         # serial / branched: 512 rows 685 / 580, 1024 rows 553 / 512, 1536 rows 439 / 448: the threshold moved to 1536.)
-        self.overlap_min_batch = int(self.cfg.get("overlap_min_batch", 1536 if self.cfg["ae_form"] == "compact" else 1024))
+        # (Dense networks, end of round 3: the serial chain with the discarded forwards paired into their neighbours' launches
+        # wins at every size -- 919 against 873 steps/s at 1024 rows, 657 / 601 at 2048, 465 / 457 at 4096: no branches.)
+        self.overlap_min_batch = int(self.cfg.get("overlap_min_batch", 1536 if self.cfg["ae_form"] == "compact" else 1 << 30))
         self._branch = True
         # one more stream for whole FORWARD chains whose result the step does not wait for (the two forwards
         # the reference runs only for their BatchNorm / RNG side effects): they run beside the critical chain

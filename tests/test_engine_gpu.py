@@ -293,6 +293,8 @@ def test_p2_teacher_forced_branched_graph_b4096(case):
 
 def _p2(case, steps, use_graph):
     g, cfg, spec, aux = load_case(case)
+    if use_graph and cfg["ae_form"] == "FC":
+        cfg = dict(cfg, overlap_min_batch=1024)      # the dense networks' default is the serial chain: ask for the branches
     torch.set_num_threads(1)
     seed = g["model_seed"]
     # the reference's schedule: the engine otherwise defers the decoder forward that the reference runs (and discards)
@@ -796,6 +798,8 @@ def test_branched_graph_is_bitwise_eager_b4096(ae_form, depth):
     streams) crashed inside ``hipGraphLaunch`` on ROCm 7.0 / 7.2 in long test sessions (nets_conv.py, fork_wgrad)."""
     g, cfg, spec, aux = load_case("compact_b4096" if ae_form == "compact" else "fc_b4096")
     cfg = dict(cfg, wgrad_overlap_depth=depth)
+    if ae_form == "FC":
+        cfg["overlap_min_batch"] = 1024              # the dense networks' default is the serial chain: ask for the branches
     results = []
     for use_graph in (False, True, True):
         eng = build_engine(cfg, 777, spec, aux, use_graph=use_graph, rng_mode="philox")
